@@ -1,0 +1,182 @@
+"""ctypes binding of libchroma_hip.so (C ABI: include/chroma_hip.h).
+
+This is the only place the package touches native code.  There is deliberately no
+CPU fallback: if the shared library is missing or cannot be loaded, importing a GPU
+entry point raises immediately and says how to build it.
+"""
+import ctypes
+import os
+import sys
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_size_t, c_uint32,
+                    c_uint64, c_void_p)
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, 'libchroma_hip.so')
+
+_f32p = POINTER(c_float)
+_u32p = POINTER(c_uint32)
+_i32p = POINTER(c_int32)
+
+
+class GeometryDesc(Structure):
+    """chroma_geometry_desc"""
+    _fields_ = [
+        ('vertices', c_void_p), ('triangles', c_void_p), ('material_codes', c_void_p),
+        ('solid_id_map', c_void_p), ('colors', c_void_p),
+        ('nvertices', c_uint32), ('ntriangles', c_uint32),
+        ('nodes', c_void_p), ('nnodes', c_uint32),
+        ('world_origin', c_float * 3), ('world_scale', c_float),
+        ('wavelength_n', c_uint32), ('wavelength_start', c_float), ('wavelength_step', c_float),
+        ('time_n', c_uint32), ('time_start', c_float), ('time_step', c_float),
+        ('nmaterials', c_uint32),
+        ('mat_refractive_index', c_void_p), ('mat_absorption_length', c_void_p),
+        ('mat_scattering_length', c_void_p), ('mat_num_comp', c_void_p), ('mat_comp_offset', c_void_p),
+        ('ncomp_total', c_uint32),
+        ('comp_reemission_prob', c_void_p), ('comp_reemission_wvl_cdf', c_void_p),
+        ('comp_absorption_length', c_void_p), ('comp_reemission_time_cdf', c_void_p),
+        ('nsurfaces', c_uint32),
+        ('surf_detect', c_void_p), ('surf_absorb', c_void_p), ('surf_reemit', c_void_p),
+        ('surf_reflect_diffuse', c_void_p), ('surf_reflect_specular', c_void_p),
+        ('surf_eta', c_void_p), ('surf_k', c_void_p), ('surf_reemission_cdf', c_void_p),
+        ('surf_model', c_void_p), ('surf_transmissive', c_void_p), ('surf_thickness', c_void_p),
+        ('surf_dichroic_index', c_void_p),
+        ('ndichroic', c_uint32),
+        ('dichroic_nangles', c_void_p), ('dichroic_offset', c_void_p),
+        ('ndichroic_angles_total', c_uint32),
+        ('dichroic_angles', c_void_p), ('dichroic_reflect', c_void_p), ('dichroic_transmit', c_void_p),
+        ('solid_id_to_channel_index', c_void_p),
+        ('nsolids', c_uint32), ('nchannels', c_uint32),
+    ]
+
+
+class PhotonArrays(Structure):
+    """chroma_photon_arrays (device or host pointers, depending on the callee)"""
+    _fields_ = [('pos', c_void_p), ('dir', c_void_p), ('pol', c_void_p), ('wavelengths', c_void_p),
+                ('t', c_void_p), ('flags', c_void_p), ('last_hit_triangles', c_void_p),
+                ('weights', c_void_p), ('evidx', c_void_p), ('rng_counters', c_void_p)]
+
+
+class Rng(Structure):
+    """chroma_rng"""
+    _fields_ = [('seed', c_uint64), ('photon_id_base', c_uint64)]
+
+
+class PropagateStats(Structure):
+    """chroma_propagate_stats"""
+    _fields_ = [('photon_steps', c_uint64), ('nodes_visited', c_uint64), ('triangles_tested', c_uint64),
+                ('launches', c_uint64), ('stack_overflows', c_uint64), ('kernel_ms', c_double)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# name -> (restype, argtypes); every symbol include/chroma_hip.h declares
+SIGNATURES = {
+    'chroma_last_error': (c_char_p, []),
+    'chroma_version': (c_char_p, []),
+    'chroma_device_count': (c_int32, [POINTER(c_int32)]),
+    'chroma_init': (c_int32, [c_int32, POINTER(c_void_p)]),
+    'chroma_shutdown': (c_int32, [c_void_p]),
+    'chroma_synchronize': (c_int32, [c_void_p]),
+    'chroma_mem_info': (c_int32, [c_void_p, POINTER(c_size_t), POINTER(c_size_t)]),
+    'chroma_device_name': (c_int32, [c_void_p, c_char_p, c_size_t]),
+    'chroma_malloc': (c_int32, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    'chroma_free': (c_int32, [c_void_p, c_void_p]),
+    'chroma_memcpy_htod': (c_int32, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'chroma_memcpy_dtoh': (c_int32, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'chroma_memcpy_dtod': (c_int32, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'chroma_memset32': (c_int32, [c_void_p, c_void_p, c_uint32, c_size_t]),
+    'chroma_geometry_create': (c_int32, [c_void_p, POINTER(GeometryDesc), POINTER(c_void_p)]),
+    'chroma_geometry_destroy': (c_int32, [c_void_p]),
+    'chroma_geometry_device_ptr': (c_int32, [c_void_p, c_char_p, POINTER(c_void_p), POINTER(c_size_t)]),
+    'chroma_geometry_stack_need': (c_int32, [c_void_p, POINTER(c_uint32)]),
+    'chroma_propagate_step': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, Rng,
+                                        POINTER(PhotonArrays), c_int32, c_int32, c_int32]),
+    'chroma_photon_duplicate': (c_int32, [c_void_p, c_int32, c_int32, POINTER(PhotonArrays), c_int32, c_int32]),
+    'chroma_count_photons': (c_int32, [c_void_p, c_int32, c_int32, c_uint32, c_void_p, POINTER(c_uint32)]),
+    'chroma_copy_photons': (c_int32, [c_void_p, c_int32, c_int32, c_uint32, POINTER(PhotonArrays),
+                                      POINTER(PhotonArrays), POINTER(c_uint32)]),
+    'chroma_copy_photon_queue': (c_int32, [c_void_p, c_int32, c_int32, c_void_p, POINTER(PhotonArrays),
+                                           POINTER(PhotonArrays)]),
+    'chroma_count_photon_hits': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_uint32,
+                                           POINTER(PhotonArrays), POINTER(c_uint32)]),
+    'chroma_copy_photon_hits': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_uint32, POINTER(PhotonArrays),
+                                          POINTER(PhotonArrays), c_void_p, POINTER(c_uint32)]),
+    'chroma_distance_to_mesh': (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'chroma_propagate': (c_int32, [c_void_p, c_void_p, POINTER(PhotonArrays), c_uint64, c_uint32, Rng, c_int32,
+                                   c_int32, c_int32, c_int32, POINTER(PropagateStats), POINTER(c_int32)]),
+    'chroma_channel_hits': (c_int32, [c_void_p, c_void_p, c_uint64, c_uint32, POINTER(PhotonArrays),
+                                      c_void_p, c_void_p]),
+    'chroma_generate_bomb': (c_int32, [c_void_p, POINTER(PhotonArrays), c_uint64, c_uint64, c_uint64,
+                                       POINTER(c_float), c_float, c_float]),
+    'chroma_bvh_build': (c_int32, [c_void_p, c_uint32, c_void_p, c_uint32, POINTER(c_float), c_float, c_int32,
+                                   POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint32)]),
+    'chroma_bvh_fetch': (c_int32, [c_void_p, c_void_p, c_void_p]),
+    'chroma_bvh_free': (c_int32, [c_void_p]),
+    'chroma_propagate_stats_read': (c_int32, [c_void_p, POINTER(PropagateStats)]),
+    'chroma_set_counting': (c_int32, [c_void_p, c_int32]),
+}
+
+_lib = None
+
+
+class ChromaError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libchroma_hip.so once; fail loudly when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBRARY_PATH):
+        raise ChromaError(
+            'libchroma_hip.so is not built (%s missing).  Build it with '
+            '`python -c "import __graft_entry__ as g; g.build()"` or `make -C chroma_amd/csrc`.  '
+            'There is no CPU fallback.' % LIBRARY_PATH)
+    # torch ships its own libamdhip64 under the same SONAME; if it is going to be used in this
+    # process it has to be loaded first so that both sides share one HIP runtime.
+    lib = ctypes.CDLL(LIBRARY_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError = symbol missing: also loud
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().chroma_last_error()
+        raise ChromaError('libchroma_hip error %d: %s' % (rc, msg.decode() if msg else '?'))
+
+
+def ptr(arr):
+    """c_void_p of a C-contiguous NumPy array (or None)."""
+    if arr is None:
+        return None
+    return arr.ctypes.data_as(c_void_p)
+
+
+def bvh_build(vertices, triangles, world_origin, world_scale, target_degree=3):
+    """Host-side BVH build.  Returns (nodes as structured uint4 array, layer bounds)."""
+    from chroma_amd.bvh.bvh import uint4
+    lib = load()
+    vertices = np.ascontiguousarray(vertices, dtype=np.float32)
+    triangles = np.ascontiguousarray(triangles, dtype=np.uint32)
+    origin = (c_float * 3)(*[float(x) for x in world_origin])
+    handle = c_void_p()
+    nnodes = c_uint64()
+    nlayers = c_uint32()
+    check(lib.chroma_bvh_build(ptr(vertices), len(vertices), ptr(triangles), len(triangles), origin,
+                               c_float(float(world_scale)), int(target_degree),
+                               ctypes.byref(handle), ctypes.byref(nnodes), ctypes.byref(nlayers)))
+    try:
+        nodes = np.empty(nnodes.value, dtype=uint4)
+        bounds = np.empty(nlayers.value + 1, dtype=np.uint64)
+        check(lib.chroma_bvh_fetch(handle, ptr(nodes), ptr(bounds)))
+    finally:
+        lib.chroma_bvh_free(handle)
+    return nodes, bounds.astype(np.int64)

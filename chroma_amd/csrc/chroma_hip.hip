@@ -1,0 +1,1006 @@
+// chroma_hip.hip -- kernels and C ABI of libchroma_hip.so (gfx950 / MI355X only).
+//
+// One photon per lane, 64-lane workgroups (one wavefront each) for the propagate kernel so a
+// workgroup retires as soon as its own photons are done; survivors are re-queued with one atomic
+// per wave (ballot compaction).  See DESIGN.md for the data layout and the kernel inventory.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "propagate_device.h"
+
+// ---------------------------------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int set_error(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return set_error((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct chroma_ctx {
+    int device;
+    hipStream_t stream;
+    // queue ping-pong buffers for chroma_propagate (n+1 words each)
+    uint32_t *queue_a = nullptr, *queue_b = nullptr;
+    size_t queue_capacity = 0;
+    // small device scratch: [0..3] DeviceCounters, then misc words
+    DeviceCounters *d_counters = nullptr;
+    uint32_t *d_words = nullptr;        // 16 words
+    uint32_t *h_words = nullptr;        // pinned mirror
+    int counting = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+
+struct chroma_geometry {
+    chroma_ctx *ctx;
+    GeoView view;
+    std::vector<void *> allocations;
+    void *d_vertices = nullptr, *d_triangles = nullptr, *d_material_codes = nullptr, *d_colors = nullptr;
+    size_t nvertices = 0, ntriangles = 0, nnodes = 0;
+    uint32_t stack_need = 0;
+    size_t device_bytes = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+#define PROP_BLOCK 64
+
+// propagate (chroma/cuda/propagate.cu:217-319)
+template <int STACK_N, bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK) void
+k_propagate(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
+            uint32_t *output_queue, uint64_t seed, uint64_t id_base, int max_steps, int use_weights,
+            int scatter_first, DeviceCounters *counters)
+{
+    __shared__ uint32_t s_stack[STACK_N * PROP_BLOCK];
+    uint32_t *stack = s_stack + threadIdx.x;
+
+    int id = blockIdx.x * PROP_BLOCK + threadIdx.x;
+    bool alive = false;
+    uint32_t photon_id = 0;
+    LaneCounters cnt = {0, 0, 0, 0};
+
+    if (id < nthreads) {
+        photon_id = input_queue ? input_queue[first_photon + id] : (uint32_t)(first_photon + id);
+        Photon p;
+        p.position = load3(pv.pos, photon_id);
+        p.direction = load3(pv.dir, photon_id);
+        p.direction = p.direction / norm(p.direction);
+        p.polarization = load3(pv.pol, photon_id);
+        p.polarization = p.polarization / norm(p.polarization);
+        p.wavelength = pv.wavelengths[photon_id];
+        p.time = pv.t[photon_id];
+        p.last_hit_triangle = pv.last_hit_triangles[photon_id];
+        p.history = pv.flags[photon_id];
+        p.weight = pv.weights[photon_id];
+        p.evidx = pv.evidx[photon_id];
+
+        if (!(p.history & CHROMA_TERMINAL_MASK)) {
+            cm_rng rng;
+            cm_rng_init(&rng, seed, id_base + photon_id, pv.rng_counters[photon_id]);
+            State s;
+            int steps = 0;
+            while (steps < max_steps) {
+                steps++;
+                if (cm_isnan(p.direction.x * p.direction.y * p.direction.z * p.position.x * p.position.y * p.position.z)) {
+                    p.history |= CHROMA_NO_HIT | CHROMA_NAN_ABORT;
+                    break;
+                }
+                if (COUNT) cnt.steps++;
+                fill_state<STACK_N, PROP_BLOCK, COUNT>(s, p, g, stack, cnt);
+                if (p.last_hit_triangle == -1) break;
+
+                int command = propagate_to_boundary(p, s, rng, g, use_weights != 0, scatter_first);
+                scatter_first = 0;
+                if (command == CMD_BREAK) break;
+                if (command == CMD_CONTINUE) continue;
+
+                if (s.surface_index != -1) {
+                    command = propagate_at_surface(p, s, rng, g, use_weights != 0);
+                    if (command == CMD_BREAK) break;
+                    if (command == CMD_CONTINUE) continue;
+                }
+                propagate_at_boundary(p, s, rng);
+            }
+            pv.rng_counters[photon_id] = rng.counter;
+            store3(pv.pos, photon_id, p.position);
+            store3(pv.dir, photon_id, p.direction);
+            store3(pv.pol, photon_id, p.polarization);
+            pv.wavelengths[photon_id] = p.wavelength;
+            pv.t[photon_id] = p.time;
+            pv.flags[photon_id] = p.history;
+            pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
+            pv.weights[photon_id] = p.weight;
+            pv.evidx[photon_id] = p.evidx;
+            alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
+        }
+    }
+    if (output_queue) wave_queue_append(output_queue, alive, photon_id);
+
+    if (COUNT || true) {
+        // overflows are always reported; the visit counters only in COUNT builds
+        unsigned long long ov = wave_sum_u64(cnt.overflows);
+        if (COUNT) {
+            unsigned long long st = wave_sum_u64(cnt.steps);
+            unsigned long long nd = wave_sum_u64(cnt.nodes);
+            unsigned long long tr = wave_sum_u64(cnt.tris);
+            if (lane_id() == 0) {
+                atomicAdd(&counters->photon_steps, st);
+                atomicAdd(&counters->nodes_visited, nd);
+                atomicAdd(&counters->triangles_tested, tr);
+            }
+        }
+        if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
+    }
+}
+
+// initial queue of GPUPhotons.propagate (chroma/gpu/photon.py:206-216): slot 0 unused counter,
+// then photon ids with the ncopies clones of a photon next to each other.
+__global__ void k_init_queue(uint32_t *queue, uint64_t n, uint32_t ncopies, uint32_t true_n)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) queue[0] = 0;
+    if (j < n) {
+        uint32_t copy = (uint32_t)(j % ncopies);
+        uint32_t idx = (uint32_t)(j / ncopies);
+        queue[1 + j] = idx + copy * true_n;
+    }
+}
+
+__global__ void k_set_word(uint32_t *p, uint32_t v) { *p = v; }
+
+// OR of (flags & mask) over all photons -> one word (abort warning, photon.py:254)
+__global__ void k_flags_or(const uint32_t *flags, uint64_t n, uint32_t mask, uint32_t *out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i < n; i += stride) acc |= flags[i] & mask;
+    if (__ballot(acc != 0)) {
+        for (int off = 32; off > 0; off >>= 1) acc |= __shfl_down(acc, off);
+        if (lane_id() == 0 && acc) atomicOr(out, acc);
+    }
+}
+
+__device__ inline void copy_photon(const PhotonView &src, size_t i, const PhotonView &dst, size_t o)
+{
+    store3(dst.pos, o, load3(src.pos, i));
+    store3(dst.dir, o, load3(src.dir, i));
+    store3(dst.pol, o, load3(src.pol, i));
+    dst.wavelengths[o] = src.wavelengths[i];
+    dst.t[o] = src.t[i];
+    dst.flags[o] = src.flags[i];
+    dst.last_hit_triangles[o] = src.last_hit_triangles[i];
+    dst.weights[o] = src.weights[i];
+    dst.evidx[o] = src.evidx[i];
+    if (dst.rng_counters && src.rng_counters) dst.rng_counters[o] = src.rng_counters[i];
+}
+
+// photon_duplicate (chroma/cuda/propagate.cu:13-52)
+__global__ void k_photon_duplicate(PhotonView pv, int first_photon, int nthreads, int copies, int stride)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nthreads) return;
+    size_t photon_id = (size_t)first_photon + id;
+    for (int i = 1; i <= copies; i++) copy_photon(pv, photon_id, pv, photon_id + (size_t)stride * i);
+}
+
+// count_photons (propagate.cu:54-79): one atomic per wave
+__global__ void k_count_photons(const uint32_t *flags, int first_photon, int nthreads, uint32_t target_flag, uint32_t *counter)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    bool pred = (id < nthreads) && (flags[first_photon + id] & target_flag);
+    unsigned long long mask = __ballot(pred);
+    if (mask && lane_id() == (unsigned)__ffsll((long long)mask) - 1u) atomicAdd(counter, (uint32_t)__popcll(mask));
+}
+
+__device__ inline uint32_t wave_reserve(uint32_t *counter, bool pred, bool &any)
+{
+    unsigned long long mask = __ballot(pred);
+    any = mask != 0ull;
+    if (!any) return 0;
+    unsigned lane = lane_id();
+    unsigned leader = (unsigned)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// copy_photons (propagate.cu:81-114)
+__global__ void k_copy_photons(PhotonView src, PhotonView dst, int first_photon, int nthreads, uint32_t target_flag, uint32_t *counter)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    bool pred = (id < nthreads) && (src.flags[first_photon + id] & target_flag);
+    bool any;
+    uint32_t off = wave_reserve(counter, pred, any);
+    if (pred) copy_photon(src, (size_t)first_photon + id, dst, off);
+}
+
+// copy_photon_queue (propagate.cu:116-144)
+__global__ void k_copy_photon_queue(PhotonView src, PhotonView dst, int first_photon, int nthreads, const uint32_t *queue)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nthreads) return;
+    size_t offset = (size_t)first_photon + id;
+    copy_photon(src, queue[offset], dst, offset);
+}
+
+__device__ inline int hit_channel(const GeoView &g, uint32_t history, int triangle_id, uint32_t detection_state)
+{
+    if (!(history & detection_state)) return -1;
+    if (triangle_id <= -1) return -1;
+    uint32_t solid_id = g.solid_id_map[triangle_id];
+    return g.solid_id_to_channel_index[solid_id];
+}
+
+// count_photon_hits (propagate.cu:147-174)
+__global__ void k_count_hits(GeoView g, const uint32_t *flags, const int32_t *last_hit, int first_photon, int nphotons,
+                             uint32_t detection_state, uint32_t *counter)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    bool pred = false;
+    if (id < nphotons) pred = hit_channel(g, flags[first_photon + id], last_hit[first_photon + id], detection_state) >= 0;
+    unsigned long long mask = __ballot(pred);
+    if (mask && lane_id() == (unsigned)__ffsll((long long)mask) - 1u) atomicAdd(counter, (uint32_t)__popcll(mask));
+}
+
+// copy_photon_hits (propagate.cu:176-214)
+__global__ void k_copy_hits(GeoView g, PhotonView src, PhotonView dst, int32_t *channels, int first_photon, int nphotons,
+                            uint32_t detection_state, uint32_t *counter)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    int ch = -1;
+    if (id < nphotons) ch = hit_channel(g, src.flags[first_photon + id], src.last_hit_triangles[first_photon + id], detection_state);
+    bool pred = ch >= 0, any;
+    uint32_t off = wave_reserve(counter, pred, any);
+    if (pred) {
+        copy_photon(src, (size_t)first_photon + id, dst, off);
+        channels[off] = ch;
+    }
+}
+
+// per-channel hit count + earliest time (float bits; non-negative times only, cuda/daq.cu:5-20)
+__global__ void k_channel_hits(GeoView g, const uint32_t *flags, const int32_t *last_hit, const float *t, uint64_t n,
+                               uint32_t detection_state, uint32_t *hit_count, uint32_t *earliest)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int ch = hit_channel(g, flags[i], last_hit[i], detection_state);
+    if (ch >= 0) {
+        atomicAdd(&hit_count[ch], 1u);
+        if (earliest) atomicMin(&earliest[ch], __float_as_uint(t[i]));
+    }
+}
+
+// distance_to_mesh (chroma/cuda/mesh.h:124-151)
+template <int STACK_N, bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK) void
+k_distance_to_mesh(GeoView g, int nthreads, const float *origin, const float *direction, float *distance_out,
+                   int32_t *triangle_out, DeviceCounters *counters)
+{
+    __shared__ uint32_t s_stack[STACK_N * PROP_BLOCK];
+    int id = blockIdx.x * PROP_BLOCK + threadIdx.x;
+    LaneCounters cnt = {0, 0, 0, 0};
+    if (id < nthreads) {
+        v3 o = load3(origin, id);
+        v3 d = load3(direction, id);
+        d = d / norm(d);
+        float dist;
+        int tri = intersect_mesh<STACK_N, PROP_BLOCK, COUNT>(g, o, d, dist, -1, s_stack + threadIdx.x, cnt);
+        if (tri != -1) distance_out[id] = dist;
+        if (triangle_out) triangle_out[id] = tri;
+    }
+    unsigned long long ov = wave_sum_u64(cnt.overflows);
+    if (COUNT) {
+        unsigned long long nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        if (lane_id() == 0) { atomicAdd(&counters->nodes_visited, nd); atomicAdd(&counters->triangles_tested, tr); }
+    }
+    if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
+}
+
+// isotropic photon bomb (chroma/benchmark.py:77-83 with chroma/sample.py:16-30's formulas)
+__global__ void k_generate_bomb(PhotonView pv, uint64_t n, uint64_t seed, uint64_t id_base, float px, float py, float pz,
+                                float wl_lo, float wl_hi)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cm_rng rng;
+    cm_rng_init(&rng, seed, 0xB0B0000000000000ull + id_base + i, 0);
+    v3 dir = uniform_sphere(rng);
+    v3 aux = uniform_sphere(rng);
+    v3 pol = cross(aux, dir);
+    pol = pol / norm(pol);
+    float wl = (wl_hi > wl_lo) ? uniform(rng, wl_lo, wl_hi) : wl_lo;
+    store3(pv.pos, i, mk3(px, py, pz));
+    store3(pv.dir, i, dir);
+    store3(pv.pol, i, pol);
+    pv.wavelengths[i] = wl;
+    pv.t[i] = 0.0f;
+    pv.flags[i] = 0u;
+    pv.last_hit_triangles[i] = -1;
+    pv.weights[i] = 1.0f;
+    pv.evidx[i] = 0u;
+    pv.rng_counters[i] = 0u;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------------------
+static PhotonView to_view(const chroma_photon_arrays *a)
+{
+    PhotonView v;
+    v.pos = a->pos; v.dir = a->dir; v.pol = a->pol; v.wavelengths = a->wavelengths; v.t = a->t;
+    v.flags = a->flags; v.last_hit_triangles = a->last_hit_triangles; v.weights = a->weights;
+    v.evidx = a->evidx; v.rng_counters = a->rng_counters;
+    return v;
+}
+
+static int check_photons(const chroma_photon_arrays *a, bool need_rng)
+{
+    if (!a || !a->pos || !a->dir || !a->pol || !a->wavelengths || !a->t || !a->flags || !a->last_hit_triangles ||
+        !a->weights || !a->evidx || (need_rng && !a->rng_counters))
+        return set_error(CHROMA_ERR_INVALID, "photon arrays: null pointer");
+    return CHROMA_OK;
+}
+
+static const int STACK_VARIANTS[] = {32, 64, 128};
+
+template <bool COUNT>
+static int launch_propagate_t(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, int first, int nthreads,
+                              const uint32_t *in_q, uint32_t *out_q, chroma_rng rng, int max_steps, int use_weights,
+                              int scatter_first)
+{
+    dim3 grid((unsigned)((nthreads + PROP_BLOCK - 1) / PROP_BLOCK)), block(PROP_BLOCK);
+    uint32_t need = geom->stack_need;
+#define LAUNCH(N)                                                                                         \
+    hipLaunchKernelGGL((k_propagate<N, COUNT>), grid, block, 0, ctx->stream, geom->view, pv, first, nthreads, \
+                       in_q, out_q, rng.seed, rng.photon_id_base, max_steps, use_weights, scatter_first, ctx->d_counters)
+    if (need <= 32) LAUNCH(32);
+    else if (need <= 64) LAUNCH(64);
+    else if (need <= 128) LAUNCH(128);
+    else return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the 128 supported", need);
+#undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+static int launch_propagate(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, int first, int nthreads,
+                            const uint32_t *in_q, uint32_t *out_q, chroma_rng rng, int max_steps, int use_weights,
+                            int scatter_first)
+{
+    if (nthreads <= 0) return CHROMA_OK;
+    if (ctx->counting)
+        return launch_propagate_t<true>(ctx, geom, pv, first, nthreads, in_q, out_q, rng, max_steps, use_weights, scatter_first);
+    return launch_propagate_t<false>(ctx, geom, pv, first, nthreads, in_q, out_q, rng, max_steps, use_weights, scatter_first);
+}
+
+template <class T>
+static int upload(chroma_geometry *g, const T *host, size_t count, const T **dev_out)
+{
+    *dev_out = nullptr;
+    size_t bytes = std::max(count, (size_t)1) * sizeof(T);
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    g->allocations.push_back(d);
+    g->device_bytes += bytes;
+    if (count && host) HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(d, 0, bytes));
+    *dev_out = (const T *)d;
+    return CHROMA_OK;
+}
+
+// Worst-case number of simultaneously live stack entries of the depth-first walk in
+// intersect_mesh for this tree (every box test succeeding).  Children always have larger
+// indices than their parent (layers are stored root first), so one backward sweep suffices.
+static uint32_t compute_stack_need(const uint32_t *nodes, size_t nnodes)
+{
+    std::vector<uint16_t> need(nnodes, 0);
+    for (size_t i = nnodes; i-- > 0;) {
+        uint32_t w = nodes[4 * i + 3];
+        uint32_t nchild = w >> CHROMA_CHILD_BITS, first = w & ~CHROMA_NCHILD_MASK;
+        if (nchild == 0) continue;
+        if ((size_t)first + nchild > nnodes || first <= i) { need[i] = 0xFFFF; continue; }
+        uint32_t rank = 0, best = 0;
+        for (uint32_t j = 0; j < nchild; j++) {
+            size_t c = (size_t)first + j;
+            bool internal = (nodes[4 * c + 3] >> CHROMA_CHILD_BITS) != 0;
+            if (internal) {
+                best = std::max(best, rank + (uint32_t)need[c]);
+                rank++;
+            }
+        }
+        best = std::max(best, rank);
+        need[i] = (uint16_t)std::min(best, 0xFFFFu);
+    }
+    return std::max<uint32_t>(1, need[0]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *chroma_last_error(void) { return g_last_error.c_str(); }
+const char *chroma_version(void) { return "chroma_hip 0.1 (gfx950)"; }
+
+int chroma_device_count(int *count)
+{
+    if (!count) return set_error(CHROMA_ERR_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return set_error(CHROMA_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return CHROMA_OK;
+}
+
+int chroma_init(int device, chroma_ctx **out)
+{
+    if (!out) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        return set_error(CHROMA_ERR_NO_DEVICE, "no HIP device available (libchroma_hip needs an MI355X/gfx950 GPU)");
+    if (device < 0) device = 0;
+    if (device >= n) return set_error(CHROMA_ERR_INVALID, "device %d out of range (%d devices)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    chroma_ctx *ctx = new chroma_ctx;
+    ctx->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void **)&ctx->d_counters, sizeof(DeviceCounters)));
+    HIP_TRY(hipMemset(ctx->d_counters, 0, sizeof(DeviceCounters)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_words, 16 * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(ctx->d_words, 0, 16 * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_words, 16 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipEventCreate(&ctx->ev_start));
+    HIP_TRY(hipEventCreate(&ctx->ev_stop));
+    *out = ctx;
+    return CHROMA_OK;
+}
+
+int chroma_shutdown(chroma_ctx *ctx)
+{
+    if (!ctx) return CHROMA_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->queue_a) hipFree(ctx->queue_a);
+    if (ctx->queue_b) hipFree(ctx->queue_b);
+    hipFree(ctx->d_counters);
+    hipFree(ctx->d_words);
+    hipHostFree(ctx->h_words);
+    hipEventDestroy(ctx->ev_start);
+    hipEventDestroy(ctx->ev_stop);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CHROMA_OK;
+}
+
+int chroma_synchronize(chroma_ctx *ctx)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CHROMA_OK;
+}
+
+int chroma_mem_info(chroma_ctx *ctx, size_t *free_bytes, size_t *total_bytes)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return CHROMA_OK;
+}
+
+int chroma_device_name(chroma_ctx *ctx, char *buf, size_t buflen)
+{
+    if (!ctx || !buf || !buflen) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return CHROMA_OK;
+}
+
+int chroma_malloc(chroma_ctx *ctx, size_t nbytes, void **d_ptr)
+{
+    if (!ctx || !d_ptr) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(d_ptr, std::max(nbytes, (size_t)4)));
+    return CHROMA_OK;
+}
+
+int chroma_free(chroma_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    if (d_ptr) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(d_ptr)); }
+    return CHROMA_OK;
+}
+
+int chroma_memcpy_htod(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    if (nbytes == 0) return CHROMA_OK;
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CHROMA_OK;
+}
+
+int chroma_memcpy_dtoh(chroma_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    if (nbytes == 0) return CHROMA_OK;
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CHROMA_OK;
+}
+
+int chroma_memcpy_dtod(chroma_ctx *ctx, void *d_dst, const void *d_src, size_t nbytes)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    if (nbytes == 0) return CHROMA_OK;
+    HIP_TRY(hipMemcpyAsync(d_dst, d_src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return CHROMA_OK;
+}
+
+int chroma_memset32(chroma_ctx *ctx, void *d_dst, uint32_t value, size_t count)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    if (count == 0) return CHROMA_OK;
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_dst, (int)value, count, ctx->stream));
+    return CHROMA_OK;
+}
+
+// ---- geometry -------------------------------------------------------------------------------------
+int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chroma_geometry **out)
+{
+    if (!ctx || !d || !out) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (!d->vertices || !d->triangles || !d->material_codes || !d->nodes || d->nnodes == 0 || d->ntriangles == 0)
+        return set_error(CHROMA_ERR_INVALID, "geometry: missing mesh or BVH arrays");
+    if (d->wavelength_n < 2 || d->nmaterials == 0 || d->nmaterials > 127 || d->nsurfaces > 127)
+        return set_error(CHROMA_ERR_INVALID, "geometry: bad optics table sizes (8-bit signed material/surface indices)");
+    if (!d->mat_refractive_index || !d->mat_absorption_length || !d->mat_scattering_length || !d->mat_num_comp || !d->mat_comp_offset)
+        return set_error(CHROMA_ERR_INVALID, "geometry: missing material tables");
+    // host-side shape checks the kernels rely on
+    for (size_t i = 0; i < (size_t)d->ntriangles * 3; i++)
+        if (d->triangles[i] >= d->nvertices) return set_error(CHROMA_ERR_INVALID, "triangle %zu references vertex %u >= %u", i / 3, d->triangles[i], d->nvertices);
+    for (size_t i = 0; i < d->nnodes; i++) {
+        uint32_t w = d->nodes[4 * i + 3];
+        uint32_t nchild = w >> CHROMA_CHILD_BITS, child = w & ~CHROMA_NCHILD_MASK;
+        if (nchild == 0) { if (child >= d->ntriangles) return set_error(CHROMA_ERR_INVALID, "leaf node %zu references triangle %u >= %u", i, child, d->ntriangles); }
+        else if ((size_t)child + nchild > d->nnodes || child <= i) return set_error(CHROMA_ERR_INVALID, "node %zu has a bad child range [%u, %u)", i, child, child + nchild);
+    }
+    for (size_t i = 0; i < d->ntriangles; i++) {
+        uint32_t code = d->material_codes[i];
+        int inner = (int8_t)(code >> 24), outer = (int8_t)(code >> 16), surf = (int8_t)(code >> 8);
+        if (inner < 0 || outer < 0 || inner >= (int)d->nmaterials || outer >= (int)d->nmaterials || surf < -1 || surf >= (int)d->nsurfaces)
+            return set_error(CHROMA_ERR_INVALID, "triangle %zu has material code 0x%08x outside the tables", i, code);
+        if (d->nsolids && d->solid_id_map && d->solid_id_map[i] >= d->nsolids)
+            return set_error(CHROMA_ERR_INVALID, "triangle %zu has solid id %u >= %u", i, d->solid_id_map[i], d->nsolids);
+    }
+    for (uint32_t m = 0; m < d->nmaterials; m++)
+        if (d->mat_num_comp[m] && d->mat_comp_offset[m] + d->mat_num_comp[m] > d->ncomp_total)
+            return set_error(CHROMA_ERR_INVALID, "material %u: component rows out of range", m);
+    for (uint32_t s = 0; s < d->nsurfaces; s++) {
+        if (d->surf_model[s] == CHROMA_SURFACE_DICHROIC) {
+            int di = d->surf_dichroic_index ? d->surf_dichroic_index[s] : -1;
+            if (di < 0 || di >= (int)d->ndichroic || d->dichroic_nangles[di] < 2 ||
+                d->dichroic_offset[di] + d->dichroic_nangles[di] > d->ndichroic_angles_total)
+                return set_error(CHROMA_ERR_INVALID, "surface %u: dichroic tables missing or out of range", s);
+        }
+    }
+
+    HIP_TRY(hipSetDevice(ctx->device));
+    chroma_geometry *g = new chroma_geometry;
+    g->ctx = ctx;
+    g->nvertices = d->nvertices; g->ntriangles = d->ntriangles; g->nnodes = d->nnodes;
+    GeoView &v = g->view;
+    memset(&v, 0, sizeof v);
+    int rc;
+#define UP(field, src, count) if ((rc = upload(g, src, (size_t)(count), &v.field)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; }
+    // nodes
+    { const uint4 *p; if ((rc = upload(g, (const uint4 *)d->nodes, d->nnodes, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } v.nodes = p; }
+    // 48-byte triangle records, staged in chunks
+    {
+        void *dtri = nullptr;
+        size_t bytes = (size_t)d->ntriangles * 48;
+        hipError_t e = hipMalloc(&dtri, bytes);
+        if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "hipMalloc(%zu) for triangle records: %s", bytes, hipGetErrorString(e)); }
+        g->allocations.push_back(dtri);
+        g->device_bytes += bytes;
+        const size_t CH = 1u << 22;
+        std::vector<float> stage(std::min((size_t)d->ntriangles, CH) * 12);
+        for (size_t t0 = 0; t0 < d->ntriangles; t0 += CH) {
+            size_t t1 = std::min((size_t)d->ntriangles, t0 + CH);
+            for (size_t t = t0; t < t1; t++) {
+                float *r = stage.data() + (t - t0) * 12;
+                for (int k = 0; k < 3; k++) {
+                    const float *vv = d->vertices + 3 * (size_t)d->triangles[3 * t + k];
+                    r[4 * k] = vv[0]; r[4 * k + 1] = vv[1]; r[4 * k + 2] = vv[2];
+                }
+                uint32_t code = d->material_codes[t], sid = d->solid_id_map ? d->solid_id_map[t] : 0u, zero = 0u;
+                memcpy(&r[3], &code, 4); memcpy(&r[7], &sid, 4); memcpy(&r[11], &zero, 4);
+            }
+            e = hipMemcpy((char *)dtri + t0 * 48, stage.data(), (t1 - t0) * 48, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "triangle upload: %s", hipGetErrorString(e)); }
+        }
+        v.tri = (const float4 *)dtri;
+    }
+    // API-visible copies of the mesh arrays (GPUGeometry.vertices/.triangles/.material_codes/.colors)
+    { const float *p; if ((rc = upload(g, d->vertices, (size_t)d->nvertices * 3, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_vertices = (void *)p; }
+    { const uint32_t *p; if ((rc = upload(g, d->triangles, (size_t)d->ntriangles * 3, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_triangles = (void *)p; }
+    { const uint32_t *p; if ((rc = upload(g, d->material_codes, d->ntriangles, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_material_codes = (void *)p; }
+    { const uint32_t *p; if ((rc = upload(g, d->colors, d->colors ? d->ntriangles : 0, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_colors = (void *)p; }
+    UP(solid_id_map, d->solid_id_map, d->solid_id_map ? d->ntriangles : 0);
+    size_t wn = d->wavelength_n;
+    UP(mat_refractive_index, d->mat_refractive_index, d->nmaterials * wn);
+    UP(mat_absorption_length, d->mat_absorption_length, d->nmaterials * wn);
+    UP(mat_scattering_length, d->mat_scattering_length, d->nmaterials * wn);
+    UP(mat_num_comp, d->mat_num_comp, d->nmaterials);
+    UP(mat_comp_offset, d->mat_comp_offset, d->nmaterials);
+    UP(comp_reemission_prob, d->comp_reemission_prob, d->ncomp_total * wn);
+    UP(comp_reemission_wvl_cdf, d->comp_reemission_wvl_cdf, d->ncomp_total * wn);
+    UP(comp_absorption_length, d->comp_absorption_length, d->ncomp_total * wn);
+    UP(comp_reemission_time_cdf, d->comp_reemission_time_cdf, (size_t)d->ncomp_total * d->time_n);
+    UP(surf_detect, d->surf_detect, d->nsurfaces * wn);
+    UP(surf_absorb, d->surf_absorb, d->nsurfaces * wn);
+    UP(surf_reemit, d->surf_reemit, d->nsurfaces * wn);
+    UP(surf_reflect_diffuse, d->surf_reflect_diffuse, d->nsurfaces * wn);
+    UP(surf_reflect_specular, d->surf_reflect_specular, d->nsurfaces * wn);
+    UP(surf_eta, d->surf_eta, d->nsurfaces * wn);
+    UP(surf_k, d->surf_k, d->nsurfaces * wn);
+    UP(surf_reemission_cdf, d->surf_reemission_cdf, d->nsurfaces * wn);
+    {
+        std::vector<SurfaceInfo> info(std::max<uint32_t>(d->nsurfaces, 1));
+        for (uint32_t s = 0; s < d->nsurfaces; s++)
+            info[s] = SurfaceInfo{d->surf_model[s], d->surf_transmissive[s], d->surf_thickness[s],
+                                  d->surf_dichroic_index ? d->surf_dichroic_index[s] : -1};
+        UP(surf_info, info.data(), info.size());
+    }
+    UP(dichroic_nangles, d->dichroic_nangles, d->ndichroic);
+    UP(dichroic_offset, d->dichroic_offset, d->ndichroic);
+    UP(dichroic_angles, d->dichroic_angles, d->ndichroic_angles_total);
+    UP(dichroic_reflect, d->dichroic_reflect, d->ndichroic_angles_total * wn);
+    UP(dichroic_transmit, d->dichroic_transmit, d->ndichroic_angles_total * wn);
+    UP(solid_id_to_channel_index, d->solid_id_to_channel_index, d->nsolids);
+#undef UP
+    memcpy(v.world_origin, d->world_origin, sizeof v.world_origin);
+    v.world_scale = d->world_scale;
+    v.wavelength_n = d->wavelength_n; v.wavelength_start = d->wavelength_start; v.wavelength_step = d->wavelength_step;
+    v.time_n = d->time_n; v.time_start = d->time_start; v.time_step = d->time_step;
+    v.nnodes = d->nnodes; v.ntriangles = d->ntriangles; v.nsolids = d->nsolids; v.nchannels = d->nchannels;
+
+    g->stack_need = compute_stack_need(d->nodes, d->nnodes);
+    if (g->stack_need > 128) {
+        uint32_t need = g->stack_need;
+        chroma_geometry_destroy(g);
+        return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the 128 supported", need);
+    }
+    *out = g;
+    return CHROMA_OK;
+}
+
+int chroma_geometry_destroy(chroma_geometry *g)
+{
+    if (!g) return CHROMA_OK;
+    hipSetDevice(g->ctx->device);
+    hipStreamSynchronize(g->ctx->stream);
+    for (void *p : g->allocations) hipFree(p);
+    delete g;
+    return CHROMA_OK;
+}
+
+int chroma_geometry_device_ptr(chroma_geometry *g, const char *name, void **d_ptr, size_t *nbytes)
+{
+    if (!g || !name || !d_ptr) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    std::string n(name);
+    size_t bytes = 0; void *p = nullptr;
+    if (n == "nodes") { p = (void *)g->view.nodes; bytes = g->nnodes * 16; }
+    else if (n == "vertices") { p = g->d_vertices; bytes = g->nvertices * 12; }
+    else if (n == "triangles") { p = g->d_triangles; bytes = g->ntriangles * 12; }
+    else if (n == "material_codes") { p = g->d_material_codes; bytes = g->ntriangles * 4; }
+    else if (n == "colors") { p = g->d_colors; bytes = g->ntriangles * 4; }
+    else if (n == "solid_id_map") { p = (void *)g->view.solid_id_map; bytes = g->ntriangles * 4; }
+    else if (n == "solid_id_to_channel_index") { p = (void *)g->view.solid_id_to_channel_index; bytes = (size_t)g->view.nsolids * 4; }
+    else if (n == "triangle_records") { p = (void *)g->view.tri; bytes = g->ntriangles * 48; }
+    else return set_error(CHROMA_ERR_INVALID, "unknown geometry array '%s'", name);
+    *d_ptr = p;
+    if (nbytes) *nbytes = bytes;
+    return CHROMA_OK;
+}
+
+int chroma_geometry_stack_need(chroma_geometry *g, uint32_t *entries)
+{
+    if (!g || !entries) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    *entries = g->stack_need;
+    return CHROMA_OK;
+}
+
+// ---- kernel-level entry points ------------------------------------------------------------------------
+int chroma_propagate_step(chroma_ctx *ctx, chroma_geometry *geom, int32_t first_photon, int32_t nthreads,
+                          const uint32_t *d_input_queue, uint32_t *d_output_queue, chroma_rng rng,
+                          const chroma_photon_arrays *photons, int32_t max_steps, int32_t use_weights,
+                          int32_t scatter_first)
+{
+    if (!ctx || !geom) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    int rc = check_photons(photons, true);
+    if (rc) return rc;
+    if (first_photon < 0 || nthreads < 0) return set_error(CHROMA_ERR_INVALID, "negative photon range");
+    return launch_propagate(ctx, geom, to_view(photons), first_photon, nthreads, d_input_queue, d_output_queue, rng,
+                            max_steps, use_weights, scatter_first);
+}
+
+int chroma_photon_duplicate(chroma_ctx *ctx, int32_t first_photon, int32_t nthreads,
+                            const chroma_photon_arrays *photons, int32_t copies, int32_t stride)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    int rc = check_photons(photons, false);
+    if (rc) return rc;
+    if (nthreads <= 0 || copies <= 0) return CHROMA_OK;
+    hipLaunchKernelGGL(k_photon_duplicate, dim3((nthreads + 255) / 256), dim3(256), 0, ctx->stream, to_view(photons),
+                       first_photon, nthreads, copies, stride);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+static int read_word(chroma_ctx *ctx, int slot, uint32_t *out)
+{
+    HIP_TRY(hipMemcpyAsync(ctx->h_words + slot, ctx->d_words + slot, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = ctx->h_words[slot];
+    return CHROMA_OK;
+}
+
+int chroma_count_photons(chroma_ctx *ctx, int32_t first_photon, int32_t nthreads, uint32_t target_flag,
+                         const uint32_t *d_flags, uint32_t *count)
+{
+    if (!ctx || !d_flags || !count) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 4, ctx->stream));
+    if (nthreads > 0) {
+        hipLaunchKernelGGL(k_count_photons, dim3((nthreads + 255) / 256), dim3(256), 0, ctx->stream, d_flags, first_photon,
+                           nthreads, target_flag, ctx->d_words);
+        HIP_TRY(hipGetLastError());
+    }
+    return read_word(ctx, 0, count);
+}
+
+int chroma_copy_photons(chroma_ctx *ctx, int32_t first_photon, int32_t nthreads, uint32_t target_flag,
+                        const chroma_photon_arrays *src, const chroma_photon_arrays *dst, uint32_t *ncopied)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    int rc = check_photons(src, false); if (rc) return rc;
+    rc = check_photons(dst, false); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 4, ctx->stream));
+    if (nthreads > 0) {
+        hipLaunchKernelGGL(k_copy_photons, dim3((nthreads + 255) / 256), dim3(256), 0, ctx->stream, to_view(src), to_view(dst),
+                           first_photon, nthreads, target_flag, ctx->d_words);
+        HIP_TRY(hipGetLastError());
+    }
+    uint32_t n = 0;
+    rc = read_word(ctx, 0, &n);
+    if (ncopied) *ncopied = n;
+    return rc;
+}
+
+int chroma_copy_photon_queue(chroma_ctx *ctx, int32_t first_photon, int32_t nthreads, const uint32_t *d_queue,
+                             const chroma_photon_arrays *src, const chroma_photon_arrays *dst)
+{
+    if (!ctx || !d_queue) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    int rc = check_photons(src, false); if (rc) return rc;
+    rc = check_photons(dst, false); if (rc) return rc;
+    if (nthreads <= 0) return CHROMA_OK;
+    hipLaunchKernelGGL(k_copy_photon_queue, dim3((nthreads + 255) / 256), dim3(256), 0, ctx->stream, to_view(src), to_view(dst),
+                       first_photon, nthreads, d_queue);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+int chroma_count_photon_hits(chroma_ctx *ctx, chroma_geometry *geom, int32_t first_photon, int32_t nphotons,
+                             uint32_t detection_state, const chroma_photon_arrays *photons, uint32_t *count)
+{
+    if (!ctx || !geom || !count) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (!geom->view.nsolids) return set_error(CHROMA_ERR_INVALID, "geometry has no detector channel map");
+    int rc = check_photons(photons, false); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 4, ctx->stream));
+    if (nphotons > 0) {
+        hipLaunchKernelGGL(k_count_hits, dim3((nphotons + 255) / 256), dim3(256), 0, ctx->stream, geom->view, photons->flags,
+                           photons->last_hit_triangles, first_photon, nphotons, detection_state, ctx->d_words);
+        HIP_TRY(hipGetLastError());
+    }
+    return read_word(ctx, 0, count);
+}
+
+int chroma_copy_photon_hits(chroma_ctx *ctx, chroma_geometry *geom, int32_t first_photon, int32_t nphotons,
+                            uint32_t detection_state, const chroma_photon_arrays *src, const chroma_photon_arrays *dst,
+                            int32_t *d_channels, uint32_t *ncopied)
+{
+    if (!ctx || !geom || !d_channels) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (!geom->view.nsolids) return set_error(CHROMA_ERR_INVALID, "geometry has no detector channel map");
+    int rc = check_photons(src, false); if (rc) return rc;
+    rc = check_photons(dst, false); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 4, ctx->stream));
+    if (nphotons > 0) {
+        hipLaunchKernelGGL(k_copy_hits, dim3((nphotons + 255) / 256), dim3(256), 0, ctx->stream, geom->view, to_view(src),
+                           to_view(dst), d_channels, first_photon, nphotons, detection_state, ctx->d_words);
+        HIP_TRY(hipGetLastError());
+    }
+    uint32_t n = 0;
+    rc = read_word(ctx, 0, &n);
+    if (ncopied) *ncopied = n;
+    return rc;
+}
+
+int chroma_distance_to_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthreads, const float *d_origin,
+                            const float *d_direction, float *d_distance, int32_t *d_triangle)
+{
+    if (!ctx || !geom || !d_origin || !d_direction || !d_distance) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (nthreads <= 0) return CHROMA_OK;
+    dim3 grid((unsigned)((nthreads + PROP_BLOCK - 1) / PROP_BLOCK)), block(PROP_BLOCK);
+    uint32_t need = geom->stack_need;
+#define LAUNCH(N, C) hipLaunchKernelGGL((k_distance_to_mesh<N, C>), grid, block, 0, ctx->stream, geom->view, nthreads, \
+                                        d_origin, d_direction, d_distance, d_triangle, ctx->d_counters)
+    if (ctx->counting) { if (need <= 32) LAUNCH(32, true); else if (need <= 64) LAUNCH(64, true); else LAUNCH(128, true); }
+    else { if (need <= 32) LAUNCH(32, false); else if (need <= 64) LAUNCH(64, false); else LAUNCH(128, false); }
+#undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+// ---- fused host loops -----------------------------------------------------------------------------------
+static int ensure_queues(chroma_ctx *ctx, size_t n)
+{
+    if (ctx->queue_capacity >= n + 1) return CHROMA_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->queue_a) hipFree(ctx->queue_a);
+    if (ctx->queue_b) hipFree(ctx->queue_b);
+    ctx->queue_a = ctx->queue_b = nullptr;
+    ctx->queue_capacity = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->queue_a, (n + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->queue_b, (n + 1) * sizeof(uint32_t)));
+    ctx->queue_capacity = n + 1;
+    return CHROMA_OK;
+}
+
+int chroma_propagate_stats_read(chroma_ctx *ctx, chroma_propagate_stats *stats)
+{
+    if (!ctx || !stats) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    DeviceCounters c;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(&c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ctx->d_counters, 0, sizeof c));
+    stats->photon_steps += c.photon_steps;
+    stats->nodes_visited += c.nodes_visited;
+    stats->triangles_tested += c.triangles_tested;
+    stats->stack_overflows += c.stack_overflows;
+    return CHROMA_OK;
+}
+
+int chroma_set_counting(chroma_ctx *ctx, int32_t enabled)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    ctx->counting = enabled ? 1 : 0;
+    return CHROMA_OK;
+}
+
+int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon_arrays *photons, uint64_t nphotons,
+                     uint32_t ncopies, chroma_rng rng, int32_t max_steps, int32_t use_weights, int32_t scatter_first,
+                     int32_t time_kernels, chroma_propagate_stats *stats, int32_t *aborted)
+{
+    if (!ctx || !geom) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    int rc = check_photons(photons, true); if (rc) return rc;
+    if (nphotons >= 0x7fffffffull) return set_error(CHROMA_ERR_INVALID, "at most 2^31-2 photons per call");
+    if (ncopies == 0 || nphotons % ncopies) return set_error(CHROMA_ERR_INVALID, "nphotons must be a multiple of ncopies");
+    if (aborted) *aborted = 0;
+    if (nphotons == 0 || max_steps <= 0) return CHROMA_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    rc = ensure_queues(ctx, nphotons); if (rc) return rc;
+    PhotonView pv = to_view(photons);
+    uint32_t *in_q = ctx->queue_a, *out_q = ctx->queue_b;
+
+    hipLaunchKernelGGL(k_init_queue, dim3((unsigned)((nphotons + 255) / 256)), dim3(256), 0, ctx->stream, in_q,
+                       (uint64_t)nphotons, ncopies, (uint32_t)(nphotons / ncopies));
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, out_q, 1u);
+    HIP_TRY(hipGetLastError());
+
+    double kernel_ms = 0.0;
+    uint64_t launches = 0;
+    uint64_t n = nphotons;
+    int step = 0;
+    while (step < max_steps) {
+        // finish in one launch once few photons are left (chroma/gpu/photon.py:227-230)
+        int nsteps = (n < (uint64_t)PROP_BLOCK * 16 * 8 || use_weights) ? (max_steps - step) : 1;
+        if (time_kernels) HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+        rc = launch_propagate(ctx, geom, pv, 0, (int)n, in_q + 1, out_q, rng, nsteps, use_weights, scatter_first);
+        if (rc) return rc;
+        launches++;
+        if (time_kernels) {
+            HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+            HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+            kernel_ms += ms;
+        }
+        step += nsteps;
+        scatter_first = 0;
+        if (step < max_steps) {
+            std::swap(in_q, out_q);
+            // survivors = tail - 1 (one 4-byte read per step, as photon.py:250)
+            HIP_TRY(hipMemcpyAsync(ctx->h_words + 1, in_q, 4, hipMemcpyDeviceToHost, ctx->stream));
+            hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, out_q, 1u);
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            n = (uint64_t)ctx->h_words[1] - 1;
+            if (n == 0) break;
+        }
+    }
+    // abort warning word (photon.py:254-255)
+    HIP_TRY(hipMemsetAsync(ctx->d_words + 2, 0, 4, ctx->stream));
+    {
+        unsigned blocks = (unsigned)std::min<uint64_t>((nphotons + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_flags_or, dim3(blocks), dim3(256), 0, ctx->stream, photons->flags, (uint64_t)nphotons,
+                           CHROMA_NAN_ABORT, ctx->d_words + 2);
+        HIP_TRY(hipGetLastError());
+    }
+    uint32_t word = 0;
+    rc = read_word(ctx, 2, &word); if (rc) return rc;
+    if (aborted) *aborted = (word & CHROMA_NAN_ABORT) ? 1 : 0;
+    if (stats) {
+        rc = chroma_propagate_stats_read(ctx, stats); if (rc) return rc;
+        stats->launches += launches;
+        stats->kernel_ms += kernel_ms;
+        if (stats->stack_overflows) return set_error(CHROMA_ERR_STACK, "traversal stack overflowed for %llu rays", (unsigned long long)stats->stack_overflows);
+    } else {
+        chroma_propagate_stats tmp; memset(&tmp, 0, sizeof tmp);
+        rc = chroma_propagate_stats_read(ctx, &tmp); if (rc) return rc;
+        if (tmp.stack_overflows) return set_error(CHROMA_ERR_STACK, "traversal stack overflowed for %llu rays", (unsigned long long)tmp.stack_overflows);
+    }
+    return CHROMA_OK;
+}
+
+int chroma_channel_hits(chroma_ctx *ctx, chroma_geometry *geom, uint64_t nphotons, uint32_t detection_state,
+                        const chroma_photon_arrays *photons, uint32_t *d_hit_count, uint32_t *d_earliest_time_bits)
+{
+    if (!ctx || !geom || !d_hit_count) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (!geom->view.nsolids) return set_error(CHROMA_ERR_INVALID, "geometry has no detector channel map");
+    int rc = check_photons(photons, false); if (rc) return rc;
+    if (nphotons == 0) return CHROMA_OK;
+    hipLaunchKernelGGL(k_channel_hits, dim3((unsigned)((nphotons + 255) / 256)), dim3(256), 0, ctx->stream, geom->view,
+                       photons->flags, photons->last_hit_triangles, photons->t, (uint64_t)nphotons, detection_state,
+                       d_hit_count, d_earliest_time_bits);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+int chroma_generate_bomb(chroma_ctx *ctx, const chroma_photon_arrays *photons, uint64_t nphotons, uint64_t seed,
+                         uint64_t id_base, const float pos[3], float wavelength_lo, float wavelength_hi)
+{
+    if (!ctx || !pos) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    int rc = check_photons(photons, true); if (rc) return rc;
+    if (nphotons == 0) return CHROMA_OK;
+    hipLaunchKernelGGL(k_generate_bomb, dim3((unsigned)((nphotons + 255) / 256)), dim3(256), 0, ctx->stream, to_view(photons),
+                       (uint64_t)nphotons, seed, id_base, pos[0], pos[1], pos[2], wavelength_lo, wavelength_hi);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+}  // extern "C"

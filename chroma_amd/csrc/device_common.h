@@ -1,0 +1,102 @@
+// device_common.h -- device-side types shared by the HIP kernels of libchroma_hip.so.
+//
+// Written for gfx950 (CDNA4) only: 64-wide wavefronts, one photon per lane.
+// Arithmetic follows include/chroma_math.h (the numeric contract) and is compiled with
+// -ffp-contract=off so that the CPU oracle reproduces every result bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CM_FN __host__ __device__ static inline
+#include "../../include/chroma_math.h"
+#include "../../include/chroma_hip.h"
+
+#define WAVE 64
+
+// ---- float3 algebra (operation order as chroma/cuda/linalg.h) -------------------------
+struct v3 { float x, y, z; };
+__device__ inline v3 mk3(float x, float y, float z) { return v3{x, y, z}; }
+__device__ inline v3 operator-(v3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ inline v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ inline v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ inline v3 operator*(v3 a, float c) { return mk3(a.x * c, a.y * c, a.z * c); }
+__device__ inline v3 operator*(float c, v3 a) { return mk3(c * a.x, c * a.y, c * a.z); }
+__device__ inline v3 operator/(v3 a, float c) { return mk3(a.x / c, a.y / c, a.z / c); }
+__device__ inline v3 operator/(v3 a, v3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ inline v3 operator/(float c, v3 a) { return mk3(c / a.x, c / a.y, c / a.z); }
+__device__ inline float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ inline v3 cross(v3 a, v3 b)
+{ return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ inline float norm(v3 a) { return cm_sqrtf(dot(a, a)); }
+__device__ inline v3 normalize(v3 a) { return a / norm(a); }
+
+__device__ inline v3 load3(const float *p, size_t i) { return mk3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+__device__ inline void store3(float *p, size_t i, v3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+
+// ---- device view of an uploaded geometry ------------------------------------------------
+// Layout in HBM (see DESIGN.md "Data layout"):
+//   nodes   uint4[nnodes]            16 B packed node, as chroma/cuda/geometry_types.h:57-67
+//   tri     float4[ntriangles][3]    48 B record: v0.xyz|material_code, v1.xyz|solid_id, v2.xyz|0
+//                                    (one aligned 48-B gather instead of the reference's
+//                                     12-B index fetch + three 12-B vertex gathers)
+//   tables  float[...]               optics tables, row-major [row][wavelength_n]
+struct SurfaceInfo { uint32_t model; uint32_t transmissive; float thickness; int32_t dichroic_index; };
+
+struct GeoView {
+    const uint4  *nodes;
+    const float4 *tri;
+    // materials
+    const float *mat_refractive_index, *mat_absorption_length, *mat_scattering_length;
+    const uint32_t *mat_num_comp, *mat_comp_offset;
+    const float *comp_reemission_prob, *comp_reemission_wvl_cdf, *comp_absorption_length, *comp_reemission_time_cdf;
+    // surfaces
+    const float *surf_detect, *surf_absorb, *surf_reemit, *surf_reflect_diffuse, *surf_reflect_specular,
+                *surf_eta, *surf_k, *surf_reemission_cdf;
+    const SurfaceInfo *surf_info;
+    const uint32_t *dichroic_nangles, *dichroic_offset;
+    const float *dichroic_angles, *dichroic_reflect, *dichroic_transmit;
+    // hits
+    const uint32_t *solid_id_map;
+    const int32_t  *solid_id_to_channel_index;
+    float world_origin[3];
+    float world_scale;
+    uint32_t wavelength_n; float wavelength_start, wavelength_step;
+    uint32_t time_n;       float time_start, time_step;
+    uint32_t nnodes, ntriangles, nsolids, nchannels;
+};
+
+struct PhotonView {   // device pointers of chroma_photon_arrays
+    float *pos, *dir, *pol, *wavelengths, *t;
+    uint32_t *flags; int32_t *last_hit_triangles; float *weights; uint32_t *evidx; uint32_t *rng_counters;
+};
+
+struct DeviceCounters {   // accumulated with one atomic per wave
+    unsigned long long photon_steps, nodes_visited, triangles_tested, stack_overflows;
+};
+
+// ---- wave-level helpers --------------------------------------------------------------------
+__device__ inline unsigned lane_id() { return __lane_id(); }
+
+// Append `value` for every lane with pred set: one atomic per wave, lanes keep their order.
+// queue[0] is the tail index (initially 1), as chroma/cuda/propagate.cu:315-318.
+__device__ inline void wave_queue_append(uint32_t *queue, bool pred, uint32_t value)
+{
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    unsigned lane = lane_id();
+    unsigned leader = (unsigned)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(queue, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (pred) {
+        unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+        queue[base + rank] = value;
+    }
+}
+
+__device__ inline unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}

@@ -1,0 +1,58 @@
+"""Demo 8-inch PMT with a light-collecting cone.
+
+Same construction as chroma/demo/pmt.py:7-20 (3 mm glass, R7081HQE photocathode on the
+upper half of the vacuum envelope, mirror back surface, reflective cone, nsteps=24),
+but the glass outline is an analytic 8-inch tube -- cylindrical neck, ellipsoidal
+bulb -- sampled with as many points as the digitised SNO tube drawing the reference
+ships (55 per half outline, 16 on the cone), so a PMT has the same triangle count
+(5 856 with its collector) and the demo detectors have the sizes quoted in BASELINE.md.
+Files in the reference's profile format still load through chroma_amd.pmt.build_pmt.
+"""
+import numpy as np
+
+from chroma_amd.pmt import build_pmt_from_profile, build_light_collector_from_profile
+from chroma_amd.demo.optics import water, glass, vacuum, shiny_surface, r7081hqe_photocathode
+
+NECK_RADIUS = 40.0        # mm
+BULB_RADIUS = 101.0       # mm, 8-inch tube
+BASE_Y = -184.0           # mm, bottom of the neck
+NECK_TOP_Y = -100.0       # mm, where the neck meets the bulb
+DOME_HEIGHT = 75.0        # mm, front face above the equator
+
+
+def pmt_outline():
+    """Half outline of the glass as (x, y) rows with x <= 0, base -> face, 55 points."""
+    pts = [(-0.85 * NECK_RADIUS, BASE_Y)]                      # moved onto the axis by the builder
+    for y in np.linspace(BASE_Y + 0.7, NECK_TOP_Y, 8):         # cylindrical neck
+        pts.append((-NECK_RADIUS, y))
+    # lower half of the bulb: ellipse through (NECK_RADIUS, NECK_TOP_Y) and (BULB_RADIUS, 0)
+    b_low = -NECK_TOP_Y / np.sqrt(1.0 - (NECK_RADIUS / BULB_RADIUS) ** 2)
+    phi0 = np.arcsin(NECK_TOP_Y / b_low)
+    for phi in np.linspace(phi0, 0.0, 21)[1:]:
+        pts.append((-BULB_RADIUS * np.cos(phi), b_low * np.sin(phi)))
+    # front dome: ellipse with semi-axes (BULB_RADIUS, DOME_HEIGHT)
+    for phi in np.linspace(0.0, np.pi / 2, 27)[1:-1]:
+        pts.append((-BULB_RADIUS * np.cos(phi), DOME_HEIGHT * np.sin(phi)))
+    pts.append((-0.03 * BULB_RADIUS, DOME_HEIGHT))             # moved onto the axis by the builder
+    return np.array(pts)
+
+
+def cone_outline():
+    """Light-collector profile as (x, y) rows, rim -> throat, 16 points."""
+    y = np.linspace(130.0, 22.0, 16)
+    r = 98.0 + 36.0 * ((y - 22.0) / 108.0) ** 0.8
+    return np.column_stack([-r, y])
+
+
+def build_8inch_pmt(outer_material=water, nsteps=24):
+    return build_pmt_from_profile(pmt_outline(), 3.0,   # 3 mm of glass
+                                  outer_material=outer_material, glass=glass, vacuum=vacuum,
+                                  photocathode_surface=r7081hqe_photocathode,
+                                  back_surface=shiny_surface, nsteps=nsteps)
+
+
+def build_8inch_pmt_with_lc(outer_material=water, nsteps=24):
+    pmt = build_8inch_pmt(outer_material, nsteps)
+    lc = build_light_collector_from_profile(cone_outline(), outer_material=outer_material,
+                                            surface=shiny_surface, nsteps=nsteps)
+    return pmt + lc

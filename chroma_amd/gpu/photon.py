@@ -1,0 +1,259 @@
+"""GPUPhotons: photon arrays on the device and the propagate / select / hit-extraction calls.
+
+Public interface as chroma/gpu/photon.py (GPUPhotons :13-348, GPUPhotonsSlice :351-381):
+same constructor arguments, attribute names (pos, dir, pol, wavelengths, t,
+last_hit_triangles, flags, weights, evidx, true_nphotons, ncopies) and method
+signatures.  ``nthreads_per_block`` / ``max_blocks`` are accepted and ignored: launch
+shapes are chosen by the library.  One array is new: ``rng_counters``, the number of
+uniforms each photon has consumed, which makes the Philox stream of a photon continue
+across repeated propagate() calls.
+"""
+import ctypes
+import sys
+
+import numpy as np
+
+from chroma_amd import _lib, event
+from chroma_amd.tools import profile_if_possible
+from chroma_amd.gpu.tools import (GPUArray, vec, to_float3, get_context, empty, zeros, RNGStates)
+
+_FIELDS = ('pos', 'dir', 'pol', 'wavelengths', 't', 'flags', 'last_hit_triangles', 'weights', 'evidx')
+
+
+def _structure(p):
+    """chroma_photon_arrays of device pointers for a GPUPhotons-like object."""
+    s = _lib.PhotonArrays()
+    for name in _FIELDS:
+        setattr(s, name, getattr(p, name).ptr)
+    rc = getattr(p, 'rng_counters', None)
+    s.rng_counters = rc.ptr if rc is not None else None
+    return s
+
+
+def _alloc_fields(n, ctx):
+    return dict(pos=empty(n, vec.float3, ctx), dir=empty(n, vec.float3, ctx), pol=empty(n, vec.float3, ctx),
+                wavelengths=empty(n, np.float32, ctx), t=empty(n, np.float32, ctx),
+                last_hit_triangles=empty(n, np.int32, ctx), flags=empty(n, np.uint32, ctx),
+                weights=empty(n, np.float32, ctx), evidx=empty(n, np.uint32, ctx))
+
+
+def _vec3_to_rows(a):
+    return a.view(np.float32).reshape((len(a), 3))
+
+
+class GPUPhotons(object):
+    def __init__(self, photons, ncopies=1, copy_flags=True, copy_triangles=True, copy_weights=True):
+        """Load ``photons`` (chroma_amd.event.Photons) onto the device, ``ncopies`` times."""
+        self.ctx = get_context()
+        nphotons = len(photons)
+        n = nphotons * ncopies
+        f = _alloc_fields(n, self.ctx)
+        self.pos, self.dir, self.pol = f['pos'], f['dir'], f['pol']
+        self.wavelengths, self.t = f['wavelengths'], f['t']
+        self.last_hit_triangles, self.flags, self.weights = f['last_hit_triangles'], f['flags'], f['weights']
+        # the reference allocates evidx for nphotons only although photon_duplicate writes
+        # all copies; allocate the full length
+        self.evidx = f['evidx']
+        self.rng_counters = zeros(n, np.uint32, self.ctx)
+        if not copy_triangles:
+            self.last_hit_triangles.fill(-1)
+        if not copy_flags:
+            self.flags.fill(0)
+        if not copy_weights:
+            self.weights.fill(1.0)
+
+        self.pos[:nphotons].set(to_float3(photons.pos))
+        self.dir[:nphotons].set(to_float3(photons.dir))
+        self.pol[:nphotons].set(to_float3(photons.pol))
+        self.wavelengths[:nphotons].set(photons.wavelengths.astype(np.float32))
+        self.t[:nphotons].set(photons.t.astype(np.float32))
+        if copy_triangles:
+            self.last_hit_triangles[:nphotons].set(photons.last_hit_triangles.astype(np.int32))
+        if copy_flags:
+            self.flags[:nphotons].set(photons.flags.astype(np.uint32))
+        if copy_weights:
+            self.weights[:nphotons].set(photons.weights.astype(np.float32))
+        self.evidx[:nphotons].set(photons.evidx.astype(np.uint32))
+
+        self.true_nphotons = nphotons
+        self.ncopies = ncopies
+        self._rng_base = None
+        if ncopies > 1 and nphotons > 0:
+            s = _structure(self)
+            _lib.check(self.ctx._lib.chroma_photon_duplicate(self.ctx.handle, 0, nphotons, ctypes.byref(s),
+                                                             ncopies - 1, nphotons))
+
+    # ---- host copies -------------------------------------------------------------------------
+    def get(self):
+        return event.Photons(_vec3_to_rows(self.pos.get()), _vec3_to_rows(self.dir.get()),
+                             _vec3_to_rows(self.pol.get()), self.wavelengths.get(), self.t.get(),
+                             self.last_hit_triangles.get(), self.flags.get(), self.weights.get(),
+                             self.evidx.get())
+
+    def __len__(self):
+        return self.pos.size
+
+    # ---- propagation ---------------------------------------------------------------------------
+    def _rng(self, rng_states):
+        """chroma_rng for this photon set: the id block is reserved on first use."""
+        if isinstance(rng_states, RNGStates):
+            if self._rng_base is None or getattr(self, '_rng_owner', None) is not rng_states:
+                self._rng_base = rng_states.reserve(len(self))
+                self._rng_owner = rng_states
+            return _lib.Rng(rng_states.seed, self._rng_base)
+        if isinstance(rng_states, _lib.Rng):
+            return rng_states
+        raise TypeError('rng_states must come from chroma_amd.gpu.get_rng_states()')
+
+    @profile_if_possible
+    def propagate(self, gpu_geometry, rng_states, nthreads_per_block=64, max_blocks=1024, max_steps=10,
+                  use_weights=False, scatter_first=0, track=False, stats=None, time_kernels=False):
+        """Propagate to termination or ``max_steps``, whichever comes first.  May be called
+        repeatedly to single-step.  With ``track=True`` returns (step_photon_ids, step_photons)
+        like the reference (chroma/gpu/photon.py:218-238,258-259)."""
+        nphotons = self.pos.size
+        lib, ctx = self.ctx._lib, self.ctx
+        rng = self._rng(rng_states)
+        s = _structure(self)
+        if not track:
+            st = _lib.PropagateStats()
+            aborted = ctypes.c_int32(0)
+            _lib.check(lib.chroma_propagate(ctx.handle, gpu_geometry.handle, ctypes.byref(s), nphotons,
+                                            self.ncopies, rng, int(max_steps), int(bool(use_weights)),
+                                            int(scatter_first), int(bool(time_kernels)), ctypes.byref(st),
+                                            ctypes.byref(aborted)))
+            if stats is not None:
+                for k, v in st.as_dict().items():
+                    stats[k] = stats.get(k, 0) + v
+            if aborted.value:
+                print("WARNING: ABORTED PHOTONS", file=sys.stderr)
+            return None
+
+        # tracking mode: one step per launch, queues kept on the Python side
+        input_queue = np.empty(nphotons + 1, dtype=np.uint32)
+        input_queue[0] = 0
+        for copy in range(self.ncopies):
+            input_queue[1 + copy::self.ncopies] = np.arange(self.true_nphotons, dtype=np.uint32) + copy * self.true_nphotons
+        in_q = GPUArray(nphotons + 1, np.uint32, ctx).set(input_queue)
+        out_init = np.zeros(nphotons + 1, dtype=np.uint32)
+        out_init[0] = 1
+        out_q = GPUArray(nphotons + 1, np.uint32, ctx).set(out_init)
+        step_photon_ids = [in_q[1:nphotons + 1].get()]
+        step_photons = [self.copy_queue(in_q[1:], nphotons).get()]
+        step = 0
+        while step < max_steps:
+            _lib.check(lib.chroma_propagate_step(ctx.handle, gpu_geometry.handle, 0, nphotons, in_q[1:].ptr, out_q.ptr,
+                                                 rng, ctypes.byref(s), 1, int(bool(use_weights)), int(scatter_first)))
+            step_photon_ids.append(in_q[1:nphotons + 1].get())
+            step_photons.append(self.copy_queue(in_q[1:], nphotons).get())
+            step += 1
+            scatter_first = 0
+            if step < max_steps:
+                in_q, out_q = out_q, in_q
+                out_q[:1].set(np.ones(1, dtype=np.uint32))
+                nphotons = int(in_q[:1].get()[0]) - 1
+                if nphotons == 0:
+                    break
+        ctx.synchronize()
+        if int(np.bitwise_or.reduce(self.flags.get(), initial=0)) & (1 << 31):
+            print("WARNING: ABORTED PHOTONS", file=sys.stderr)
+        return step_photon_ids, step_photons
+
+    @profile_if_possible
+    def copy_queue(self, queue_gpu, nphotons, nthreads_per_block=64, max_blocks=1024, start_photon=0):
+        """Gather the photons listed in ``queue_gpu`` (tracking mode, photon.py:261-285)."""
+        f = _alloc_fields(nphotons, self.ctx)
+        out = GPUPhotonsSlice(**f)
+        if nphotons > 0:
+            src, dst = _structure(self), _structure(out)
+            _lib.check(self.ctx._lib.chroma_copy_photon_queue(self.ctx.handle, start_photon, nphotons, queue_gpu.ptr,
+                                                              ctypes.byref(src), ctypes.byref(dst)))
+        return out
+
+    @profile_if_possible
+    def select(self, target_flag, nthreads_per_block=64, max_blocks=1024, start_photon=None, nphotons=None):
+        """New photon set with the photons whose history has ``target_flag`` set."""
+        if start_photon is None:
+            start_photon = 0
+        if nphotons is None:
+            nphotons = self.pos.size - start_photon
+        lib, ctx = self.ctx._lib, self.ctx
+        count = ctypes.c_uint32()
+        _lib.check(lib.chroma_count_photons(ctx.handle, start_photon, nphotons, int(target_flag), self.flags.ptr,
+                                            ctypes.byref(count)))
+        out = GPUPhotonsSlice(**_alloc_fields(count.value, ctx))
+        if count.value > 0:
+            src, dst = _structure(self), _structure(out)
+            ncopied = ctypes.c_uint32()
+            _lib.check(lib.chroma_copy_photons(ctx.handle, start_photon, nphotons, int(target_flag), ctypes.byref(src),
+                                               ctypes.byref(dst), ctypes.byref(ncopied)))
+            assert ncopied.value == count.value
+        return out
+
+    def get_hits(self, *args, **kwargs):
+        """dict channel -> Photons detected on that channel."""
+        flat = self.get_flat_hits(*args, **kwargs)
+        return {int(ch): flat[flat.channel == ch] for ch in np.unique(flat.channel)}
+
+    def get_flat_hits(self, gpu_detector, target_flag=(0x1 << 2), nthreads_per_block=64, max_blocks=1024,
+                      start_photon=None, nphotons=None, no_map=False):
+        """Photons with ``target_flag`` set whose last hit triangle belongs to a channel, plus
+        that channel (chroma/gpu/photon.py:107-175).  Order is unspecified, as in the reference."""
+        if start_photon is None:
+            start_photon = 0
+        if nphotons is None:
+            nphotons = self.pos.size - start_photon
+        lib, ctx = self.ctx._lib, self.ctx
+        src = _structure(self)
+        count = ctypes.c_uint32()
+        _lib.check(lib.chroma_count_photon_hits(ctx.handle, gpu_detector.handle, start_photon, nphotons, int(target_flag),
+                                                ctypes.byref(src), ctypes.byref(count)))
+        n = count.value
+        out = GPUPhotonsSlice(**_alloc_fields(n, ctx))
+        channels = empty(n, np.int32, ctx)
+        if n > 0:
+            dst = _structure(out)
+            ncopied = ctypes.c_uint32()
+            _lib.check(lib.chroma_copy_photon_hits(ctx.handle, gpu_detector.handle, start_photon, nphotons, int(target_flag),
+                                                   ctypes.byref(src), ctypes.byref(dst), channels.ptr, ctypes.byref(ncopied)))
+            assert ncopied.value == n
+        p = out.get()
+        p.channel = channels.get().astype(np.uint32) if n else np.zeros(0, dtype=np.uint32)
+        return p
+
+    def channel_hits(self, gpu_detector, target_flag=(0x1 << 2)):
+        """Per-channel (hit count, earliest hit time) of this photon set, reduced on the device.
+        This is the array that is all-reduced across GPUs."""
+        lib, ctx = self.ctx._lib, self.ctx
+        nch = gpu_detector.nchannels
+        counts = zeros(nch, np.uint32, ctx)
+        earliest = GPUArray(nch, np.uint32, ctx).fill(np.uint32(0x7f800000))
+        src = _structure(self)
+        _lib.check(lib.chroma_channel_hits(ctx.handle, gpu_detector.handle, self.pos.size, int(target_flag),
+                                           ctypes.byref(src), counts.ptr, earliest.ptr))
+        return counts, earliest
+
+    def iterate_copies(self):
+        """GPUPhotonsSlice views of the ``ncopies`` replicas."""
+        for i in range(self.ncopies):
+            w = slice(self.true_nphotons * i, self.true_nphotons * (i + 1))
+            yield GPUPhotonsSlice(pos=self.pos[w], dir=self.dir[w], pol=self.pol[w],
+                                  wavelengths=self.wavelengths[w], t=self.t[w],
+                                  last_hit_triangles=self.last_hit_triangles[w], flags=self.flags[w],
+                                  weights=self.weights[w], evidx=self.evidx[w],
+                                  rng_counters=self.rng_counters[w])
+
+
+class GPUPhotonsSlice(GPUPhotons):
+    """A view of (or a set of freshly gathered) device photon arrays; same methods as
+    GPUPhotons (chroma/gpu/photon.py:351-381)."""
+
+    def __init__(self, pos, dir, pol, wavelengths, t, last_hit_triangles, flags, weights, evidx, rng_counters=None):
+        self.ctx = pos.ctx
+        self.pos, self.dir, self.pol = pos, dir, pol
+        self.wavelengths, self.t = wavelengths, t
+        self.last_hit_triangles, self.flags, self.weights, self.evidx = last_hit_triangles, flags, weights, evidx
+        self.rng_counters = rng_counters if rng_counters is not None else zeros(len(pos), np.uint32, self.ctx)
+        self.true_nphotons = len(pos)
+        self.ncopies = 1
+        self._rng_base = None

@@ -1,0 +1,134 @@
+"""Simulation driver: batches events, propagates them on the GPU and extracts hits.
+
+Reference: chroma/sim.py:21-186 (``Simulation.__init__``, ``_simulate_batch``, ``simulate``).
+Out of scope here, as in SURVEY.md section 8: GEANT4 photon generation (``geant4_processes``
+is accepted; Event/Vertex inputs need a generator that this package does not provide), the
+PDF / likelihood entry points and the DAQ (``run_daq``).
+"""
+import os
+import time
+from timeit import default_timer as timer
+
+import numpy as np
+
+from chroma_amd import event, gpu, itertoolset
+
+
+def pick_seed():
+    """A seed mixed from the time and the process id (chroma/sim.py:16-19)."""
+    return int(time.time()) ^ (os.getpid() << 16) & 2 ** 32 - 1
+
+
+class Simulation(object):
+    def __init__(self, detector, seed=None, cuda_device=None, particle_tracking=False, photon_tracking=False,
+                 geant4_processes=0, nthreads_per_block=64, max_blocks=1024):
+        self.detector = detector
+        self.nthreads_per_block = nthreads_per_block
+        self.max_blocks = max_blocks
+        self.photon_tracking = photon_tracking
+        self.seed = pick_seed() if seed is None else seed
+        np.random.seed(self.seed % (2 ** 32))
+        self.photon_generator = None      # GEANT4 generation is outside the propagate path
+
+        self.context = gpu.create_cuda_context(cuda_device)
+        if getattr(detector, 'bvh', None) is None:
+            from chroma_amd.loader import load_bvh
+            detector.flatten()
+            detector.bvh = load_bvh(detector)
+        if hasattr(detector, 'num_channels'):
+            self.gpu_geometry = gpu.GPUDetector(detector)
+        else:
+            self.gpu_geometry = gpu.GPUGeometry(detector)
+        self.rng_states = gpu.get_rng_states(self.nthreads_per_block * self.max_blocks, seed=self.seed)
+        self.pdf_config = None
+
+    def _simulate_batch(self, batch_events, keep_photons_beg=False, keep_photons_end=False, keep_hits=True,
+                        keep_flat_hits=True, run_daq=False, max_steps=100, verbose=False):
+        """Propagate the photons of all ``batch_events`` in one go and split the results
+        back per event (by evidx).  Yields the events."""
+        t_start = timer()
+        batch_photons = event.Photons.join([ev.photons_beg for ev in batch_events])
+        bounds = np.cumsum(np.concatenate([[0], [len(ev.photons_beg) for ev in batch_events]]))
+
+        gpu_photons = gpu.GPUPhotons(batch_photons, copy_triangles=False, copy_weights=False)
+        t_copy = timer()
+        tracking = gpu_photons.propagate(self.gpu_geometry, self.rng_states,
+                                         nthreads_per_block=self.nthreads_per_block, max_blocks=self.max_blocks,
+                                         max_steps=max_steps, track=self.photon_tracking)
+        t_prop = timer()
+        if verbose:
+            print('GPU copy took %0.2f s' % (t_copy - t_start))
+            print('GPU propagate took %0.2f s' % (t_prop - t_copy))
+
+        if run_daq:
+            raise NotImplementedError('the DAQ (chroma/gpu/daq.py) is not part of this engine yet')
+        is_detector = hasattr(self.detector, 'num_channels')
+        batch_end = gpu_photons.get() if keep_photons_end else None
+        batch_hits = gpu_photons.get_flat_hits(self.gpu_geometry) if is_detector and (keep_hits or keep_flat_hits) else None
+
+        for i, (ev, lo, hi) in enumerate(zip(batch_events, bounds[:-1], bounds[1:])):
+            if not keep_photons_beg:
+                ev.photons_beg = None
+            if self.photon_tracking:
+                step_ids_list, step_photons_list = tracking
+                tracks = [[] for _ in range(hi - lo)]
+                for step_ids, step_photons in zip(step_ids_list, step_photons_list):
+                    mask = np.logical_and(step_ids >= lo, step_ids < hi)
+                    if np.count_nonzero(mask) == 0:
+                        break
+                    ids = step_ids[mask] - lo
+                    photons = step_photons[mask]
+                    for k, pid in enumerate(ids):
+                        tracks[pid].append(photons[k])
+                ev.photon_tracks = [event.Photons.join(t, concatenate=False) if len(t) > 0 else event.Photons()
+                                    for t in tracks]
+            if keep_photons_end:
+                ev.photons_end = batch_end[lo:hi]
+            if batch_hits is not None:
+                ev_hits = batch_hits[batch_hits.evidx == i]
+                if keep_hits:
+                    ev.hits = {int(ch): ev_hits[ev_hits.channel == ch] for ch in np.unique(ev_hits.channel)}
+                if keep_flat_hits:
+                    ev.flat_hits = ev_hits
+            yield ev
+
+    def simulate(self, iterable, keep_photons_beg=False, keep_photons_end=False, keep_hits=True,
+                 keep_flat_hits=True, run_daq=False, max_steps=1000, photons_per_batch=1000000, evid_start=0):
+        """Simulate Photons objects (or Events that already carry ``photons_beg``); events are
+        batched until ``photons_per_batch`` photons are collected (chroma/sim.py:141-186)."""
+        if isinstance(iterable, event.Photons):
+            first, iterable = iterable, [iterable]
+        else:
+            first, iterable = itertoolset.peek(iterable)
+        if isinstance(first, event.Photons):
+            iterable = (event.Event(photons_beg=x) for x in iterable)
+        elif isinstance(first, event.Event):
+            if first.photons_beg is None:
+                raise NotImplementedError('events without photons need the GEANT4 generator, which is out of scope')
+        else:
+            raise NotImplementedError('Vertex input needs the GEANT4 generator, which is out of scope')
+
+        kwargs = dict(keep_photons_beg=keep_photons_beg, keep_photons_end=keep_photons_end, keep_hits=keep_hits,
+                      keep_flat_hits=keep_flat_hits, run_daq=run_daq, max_steps=max_steps)
+        nphotons = 0
+        batch = []
+        evid = evid_start
+        for ev in iterable:
+            ev.id = evid
+            evid += 1
+            ev.nphotons = len(ev.photons_beg)
+            ev.photons_beg.evidx[:] = len(batch)
+            nphotons += ev.nphotons
+            batch.append(ev)
+            if nphotons >= photons_per_batch:
+                yield from self._simulate_batch(batch, **kwargs)
+                nphotons = 0
+                batch = []
+        if batch:
+            yield from self._simulate_batch(batch, **kwargs)
+
+    def __del__(self):
+        try:
+            self.context.pop()
+        except Exception:
+            pass

@@ -1,0 +1,278 @@
+/* chroma_hip.h -- C ABI of libchroma_hip.so, the MI355X (gfx950) photon-propagation engine.
+ *
+ * This is the drop-in boundary for chroma's propagate path.  In the reference the
+ * boundary is PyCUDA: Python JIT-compiles the .cu files under chroma/cuda and launches kernels by
+ * name (chroma/gpu/tools.py:14-54).  Every entry point below names the reference
+ * kernel or host routine it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw device/host pointers, sizes; no C++ or torch types.
+ *   - every function returns 0 (CHROMA_OK) or a negative chroma error / positive
+ *     hipError_t; chroma_last_error() returns a thread-local message.
+ *   - "d_" arguments are device pointers obtained from chroma_malloc(); all other
+ *     pointers are host pointers.
+ *   - all work is issued on the context's stream; entry points that return values
+ *     to the host synchronise that stream, the others are asynchronous.
+ *   - photon arrays are structure-of-arrays exactly as chroma/cuda/propagate.cu:217-226
+ *     takes them: float3 arrays are packed [n][3] floats (12-byte stride).
+ */
+#ifndef CHROMA_HIP_H
+#define CHROMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHROMA_OK                 0
+#define CHROMA_ERR_INVALID       -1   /* bad argument / shape mismatch             */
+#define CHROMA_ERR_NO_DEVICE     -2   /* no usable HIP device                      */
+#define CHROMA_ERR_STACK         -3   /* BVH needs a deeper traversal stack        */
+#define CHROMA_ERR_INTERNAL      -4
+
+/* History bits: chroma/cuda/photon.h:49-64 == chroma/event.py:5-17 */
+#define CHROMA_NO_HIT            (1u << 0)
+#define CHROMA_BULK_ABSORB       (1u << 1)
+#define CHROMA_SURFACE_DETECT    (1u << 2)
+#define CHROMA_SURFACE_ABSORB    (1u << 3)
+#define CHROMA_RAYLEIGH_SCATTER  (1u << 4)
+#define CHROMA_REFLECT_DIFFUSE   (1u << 5)
+#define CHROMA_REFLECT_SPECULAR  (1u << 6)
+#define CHROMA_SURFACE_REEMIT    (1u << 7)
+#define CHROMA_SURFACE_TRANSMIT  (1u << 8)
+#define CHROMA_BULK_REEMIT       (1u << 9)
+#define CHROMA_CHERENKOV         (1u << 10)
+#define CHROMA_SCINTILLATION     (1u << 11)
+#define CHROMA_NAN_ABORT         (1u << 31)
+/* chroma/cuda/propagate.cu:258,315 */
+#define CHROMA_TERMINAL_MASK (CHROMA_NO_HIT | CHROMA_BULK_ABSORB | CHROMA_SURFACE_DETECT | \
+                              CHROMA_SURFACE_ABSORB | CHROMA_NAN_ABORT)
+
+/* surface models: chroma/cuda/geometry_types.h:22 */
+#define CHROMA_SURFACE_DEFAULT  0
+#define CHROMA_SURFACE_COMPLEX  1
+#define CHROMA_SURFACE_WLS      2
+#define CHROMA_SURFACE_DICHROIC 3
+
+/* packed BVH node: chroma/cuda/geometry_types.h:57-59 */
+#define CHROMA_CHILD_BITS  28
+#define CHROMA_NCHILD_MASK 0xF0000000u
+
+typedef struct chroma_ctx chroma_ctx;
+typedef struct chroma_geometry chroma_geometry;
+
+/* Flat, pointer-free description of a flattened geometry + BVH + optics tables.
+ * Replaces the pointer-linked Material/Surface/DichroicProps/Geometry/Detector
+ * structs assembled byte-by-byte by chroma/gpu/geometry.py:47-253 and
+ * chroma/gpu/detector.py:17-40 (struct layouts chroma/cuda/geometry_types.h:4-82,
+ * chroma/cuda/detector.h:4-22).  All pointers are HOST pointers; the library
+ * copies what it needs.  Tables are row-major [index][wavelength_n]. */
+typedef struct chroma_geometry_desc {
+    /* mesh (chroma/gpu/geometry.py:191-209) */
+    const float    *vertices;        /* [nvertices][3]                               */
+    const uint32_t *triangles;       /* [ntriangles][3] vertex indices               */
+    const uint32_t *material_codes;  /* [ntriangles] inner<<24|outer<<16|surface<<8  */
+    const uint32_t *solid_id_map;    /* [ntriangles]                                 */
+    const uint32_t *colors;          /* [ntriangles] or NULL                         */
+    uint32_t nvertices, ntriangles;
+    /* BVH (chroma/bvh/bvh.py, chroma/cuda/geometry.h:31-47) */
+    const uint32_t *nodes;           /* [nnodes][4] packed x,y,z,w                   */
+    uint32_t nnodes;
+    float world_origin[3];
+    float world_scale;
+    /* common grids (chroma/gpu/geometry.py:15-30) */
+    uint32_t wavelength_n; float wavelength_start, wavelength_step;
+    uint32_t time_n;       float time_start, time_step;
+    /* materials (chroma/gpu/geometry.py:47-103) */
+    uint32_t nmaterials;
+    const float    *mat_refractive_index;   /* [nmaterials][wavelength_n] */
+    const float    *mat_absorption_length;
+    const float    *mat_scattering_length;
+    const uint32_t *mat_num_comp;           /* [nmaterials]                          */
+    const uint32_t *mat_comp_offset;        /* [nmaterials] first row in comp tables */
+    uint32_t ncomp_total;
+    const float    *comp_reemission_prob;     /* [ncomp_total][wavelength_n] */
+    const float    *comp_reemission_wvl_cdf;  /* [ncomp_total][wavelength_n] */
+    const float    *comp_absorption_length;   /* [ncomp_total][wavelength_n] */
+    const float    *comp_reemission_time_cdf; /* [ncomp_total][time_n]       */
+    /* surfaces (chroma/gpu/geometry.py:108-189); a None surface keeps its slot, zero-filled */
+    uint32_t nsurfaces;
+    const float    *surf_detect;            /* [nsurfaces][wavelength_n] each */
+    const float    *surf_absorb;
+    const float    *surf_reemit;
+    const float    *surf_reflect_diffuse;
+    const float    *surf_reflect_specular;
+    const float    *surf_eta;
+    const float    *surf_k;
+    const float    *surf_reemission_cdf;
+    const uint32_t *surf_model;             /* [nsurfaces] */
+    const uint32_t *surf_transmissive;
+    const float    *surf_thickness;
+    const int32_t  *surf_dichroic_index;    /* [nsurfaces] index into dichroic tables or -1 */
+    uint32_t ndichroic;
+    const uint32_t *dichroic_nangles;       /* [ndichroic]                 */
+    const uint32_t *dichroic_offset;        /* [ndichroic] first angle row */
+    uint32_t ndichroic_angles_total;
+    const float    *dichroic_angles;        /* [ndichroic_angles_total]                */
+    const float    *dichroic_reflect;       /* [ndichroic_angles_total][wavelength_n]  */
+    const float    *dichroic_transmit;      /* [ndichroic_angles_total][wavelength_n]  */
+    /* detector part (chroma/gpu/detector.py:17-40); nsolids == 0 for a plain Geometry */
+    const int32_t  *solid_id_to_channel_index; /* [nsolids] */
+    uint32_t nsolids, nchannels;
+} chroma_geometry_desc;
+
+/* The nine photon arrays of chroma/cuda/propagate.cu:220-225 plus the per-photon
+ * Philox draw counter that replaces curandState (propagate.cu:219,241,303). */
+typedef struct chroma_photon_arrays {
+    float    *pos;                 /* [n][3] mm          */
+    float    *dir;                 /* [n][3]             */
+    float    *pol;                 /* [n][3]             */
+    float    *wavelengths;         /* [n] nm             */
+    float    *t;                   /* [n] ns             */
+    uint32_t *flags;               /* [n] history bits   */
+    int32_t  *last_hit_triangles;  /* [n]                */
+    float    *weights;             /* [n]                */
+    uint32_t *evidx;               /* [n]                */
+    uint32_t *rng_counters;        /* [n] uniforms already drawn by each photon */
+} chroma_photon_arrays;
+
+/* Replaces the curandState array from get_rng_states (chroma/gpu/tools.py:75-84):
+ * the stream of photon i is Philox4x32-10 keyed by `seed`, indexed by
+ * `photon_id_base + i` (see include/chroma_math.h). */
+typedef struct chroma_rng {
+    uint64_t seed;
+    uint64_t photon_id_base;
+} chroma_rng;
+
+typedef struct chroma_propagate_stats {
+    uint64_t photon_steps;       /* loop iterations that ran a ray cast (propagate.cu:264-275)  */
+    uint64_t nodes_visited;      /* get_node calls in the child loop (cuda/mesh.h:75-76)        */
+    uint64_t triangles_tested;   /* intersect_triangle calls (cuda/mesh.h:84-86)                */
+    uint64_t launches;           /* propagate kernel launches                                   */
+    uint64_t stack_overflows;    /* rays whose traversal stack overflowed (must be 0)           */
+    double   kernel_ms;          /* HIP-event time of the propagate kernel launches, if timed   */
+} chroma_propagate_stats;
+
+const char *chroma_last_error(void);
+const char *chroma_version(void);
+
+/* ---- context: replaces create_cuda_context (chroma/gpu/tools.py:121-142) ---- */
+int chroma_device_count(int *count);
+int chroma_init(int device, chroma_ctx **ctx);
+int chroma_shutdown(chroma_ctx *ctx);
+int chroma_synchronize(chroma_ctx *ctx);
+int chroma_mem_info(chroma_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
+int chroma_device_name(chroma_ctx *ctx, char *buf, size_t buflen);
+
+/* ---- device memory: replaces pycuda.gpuarray allocation / get / set ---- */
+int chroma_malloc(chroma_ctx *ctx, size_t nbytes, void **d_ptr);
+int chroma_free(chroma_ctx *ctx, void *d_ptr);
+int chroma_memcpy_htod(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes);
+int chroma_memcpy_dtoh(chroma_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes);
+int chroma_memcpy_dtod(chroma_ctx *ctx, void *d_dst, const void *d_src, size_t nbytes);
+int chroma_memset32(chroma_ctx *ctx, void *d_dst, uint32_t value, size_t count);
+
+/* ---- geometry: replaces GPUGeometry.__init__ / GPUDetector.__init__ ---- */
+int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *desc, chroma_geometry **geom);
+int chroma_geometry_destroy(chroma_geometry *geom);
+/* device pointers of the uploaded arrays, for the GPUGeometry attributes
+ * (vertices, triangles, nodes, material_codes, colors, solid_id_map; gpu/geometry.py:191-209) */
+int chroma_geometry_device_ptr(chroma_geometry *geom, const char *name, void **d_ptr, size_t *nbytes);
+/* worst-case traversal stack entries this BVH can need (host-side tree walk) */
+int chroma_geometry_stack_need(chroma_geometry *geom, uint32_t *entries);
+
+/* ---- kernel-level entry points (one per reference kernel) ---- */
+
+/* `propagate` (chroma/cuda/propagate.cu:217-319): up to max_steps steps for the photons
+ * input_queue[first_photon .. first_photon+nthreads); survivors are appended to
+ * d_output_queue (slot 0 = tail index, initial value 1, propagate.cu:315-318).
+ * Asynchronous.  `stats` may be NULL; if given it is ACCUMULATED into on the next
+ * synchronising call (chroma_propagate_stats_read). */
+int chroma_propagate_step(chroma_ctx *ctx, chroma_geometry *geom,
+                          int32_t first_photon, int32_t nthreads,
+                          const uint32_t *d_input_queue, uint32_t *d_output_queue,
+                          chroma_rng rng, const chroma_photon_arrays *photons,
+                          int32_t max_steps, int32_t use_weights, int32_t scatter_first);
+
+/* `photon_duplicate` (chroma/cuda/propagate.cu:13-52) */
+int chroma_photon_duplicate(chroma_ctx *ctx, int32_t first_photon, int32_t nthreads,
+                            const chroma_photon_arrays *photons, int32_t copies, int32_t stride);
+
+/* `count_photons` + `copy_photons` (chroma/cuda/propagate.cu:54-114) */
+int chroma_count_photons(chroma_ctx *ctx, int32_t first_photon, int32_t nthreads,
+                         uint32_t target_flag, const uint32_t *d_flags, uint32_t *count);
+int chroma_copy_photons(chroma_ctx *ctx, int32_t first_photon, int32_t nthreads,
+                        uint32_t target_flag, const chroma_photon_arrays *src,
+                        const chroma_photon_arrays *dst, uint32_t *ncopied);
+
+/* `copy_photon_queue` (chroma/cuda/propagate.cu:116-144) */
+int chroma_copy_photon_queue(chroma_ctx *ctx, int32_t first_photon, int32_t nthreads,
+                             const uint32_t *d_queue, const chroma_photon_arrays *src,
+                             const chroma_photon_arrays *dst);
+
+/* `count_photon_hits` + `copy_photon_hits` (chroma/cuda/propagate.cu:147-214) */
+int chroma_count_photon_hits(chroma_ctx *ctx, chroma_geometry *geom, int32_t first_photon,
+                             int32_t nphotons, uint32_t detection_state,
+                             const chroma_photon_arrays *photons, uint32_t *count);
+int chroma_copy_photon_hits(chroma_ctx *ctx, chroma_geometry *geom, int32_t first_photon,
+                            int32_t nphotons, uint32_t detection_state,
+                            const chroma_photon_arrays *src, const chroma_photon_arrays *dst,
+                            int32_t *d_channels, uint32_t *ncopied);
+
+/* `distance_to_mesh` (chroma/cuda/mesh.h:124-151); d_triangle may be NULL.
+ * Rays that miss leave d_distance untouched, as in the reference. */
+int chroma_distance_to_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthreads,
+                            const float *d_origin, const float *d_direction,
+                            float *d_distance, int32_t *d_triangle);
+
+/* ---- fused host loops ---- */
+
+/* GPUPhotons.propagate (chroma/gpu/photon.py:193-259) for n photons, whole loop on the
+ * device side: queue ping-pong, survivor compaction, no per-step host copy of the photon
+ * arrays.  ncopies/true_nphotons give the interleaved initial queue order of
+ * photon.py:209-212.  Synchronises.  `stats` may be NULL.  `aborted` (may be NULL)
+ * receives 1 if any photon carries NAN_ABORT afterwards (photon.py:254-255). */
+int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon_arrays *photons,
+                     uint64_t nphotons, uint32_t ncopies, chroma_rng rng,
+                     int32_t max_steps, int32_t use_weights, int32_t scatter_first,
+                     int32_t time_kernels, chroma_propagate_stats *stats, int32_t *aborted);
+
+/* Per-channel reduction of detected photons: hit count and earliest hit time
+ * (float bits, valid for t >= 0 as in chroma/cuda/daq.cu:5-20).  The arrays
+ * (length nchannels, device) are ACCUMULATED into: zero / 0x7f800000-fill them first.
+ * This is the quantity all-reduced across GPUs. */
+int chroma_channel_hits(chroma_ctx *ctx, chroma_geometry *geom, uint64_t nphotons,
+                        uint32_t detection_state, const chroma_photon_arrays *photons,
+                        uint32_t *d_hit_count, uint32_t *d_earliest_time_bits);
+
+/* Isotropic photon bomb generated on the device (the benchmark source of
+ * chroma/benchmark.py:77-83, formulas chroma/sample.py:16-30), photon i drawn from
+ * Philox stream (seed, 0xB0B0000000000000 + id_base + i).  wavelength_hi <= wavelength_lo
+ * gives a mono-energetic bomb. */
+int chroma_generate_bomb(chroma_ctx *ctx, const chroma_photon_arrays *photons, uint64_t nphotons,
+                         uint64_t seed, uint64_t id_base, const float pos[3],
+                         float wavelength_lo, float wavelength_hi);
+
+/* ---- host-side BVH construction -------------------------------------------------------
+ * Recursive-grid builder: replaces make_recursive_grid_bvh (chroma/bvh/grid.py:11-95) and the
+ * kernels it drives -- make_leaves, make_parents_detailed, copy_and_offset, collapse_child
+ * (chroma/cuda/bvh.cu:149-203,270-308,365-384,530-543; hosts chroma/gpu/bvh.py:18-130,239-267).
+ * Runs on the host cores (no device needed).  Two-phase: build returns a handle and the sizes,
+ * fetch copies nodes ([nnodes][4] uint32) and layer bounds ([nlayers+1] uint64), free releases. */
+int chroma_bvh_build(const float *vertices, uint32_t nvertices, const uint32_t *triangles, uint32_t ntriangles,
+                     const float world_origin[3], float world_scale, int32_t target_degree,
+                     void **handle, uint64_t *nnodes, uint32_t *nlayers);
+int chroma_bvh_fetch(void *handle, uint32_t *nodes_out, uint64_t *layer_bounds_out);
+int chroma_bvh_free(void *handle);
+
+/* accumulated counters of chroma_propagate_step launches since the last read */
+int chroma_propagate_stats_read(chroma_ctx *ctx, chroma_propagate_stats *stats);
+/* enable (1) / disable (0) node/triangle visit counting in the propagate kernels */
+int chroma_set_counting(chroma_ctx *ctx, int32_t enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHROMA_HIP_H */

@@ -1,0 +1,154 @@
+"""Python access to the CPU oracle (oracle/chroma_oracle.c) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package.  It is the checker, never the thing measured or shipped: nothing under
+chroma_amd/ imports it.
+
+``variant='contract'`` loads the build whose transcendental functions come from
+include/chroma_math.h (bit-exact comparand of the HIP engine); ``variant='libm'`` the
+build against the host libm (independent check that the physics does not hinge on the
+contract's polynomials).
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_float, c_int32, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+from chroma_amd import _lib as _abi        # only for the ctypes Structure definitions of the C ABI
+from chroma_amd import event
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_libs = {}
+
+
+def build(force=False):
+    """Compile liboracle.so / liboracle_libm.so (and oracle/_ref when the reference is present)."""
+    have = all(os.path.exists(os.path.join(_HERE, n)) for n in ('liboracle.so', 'liboracle_libm.so'))
+    if have and not force:
+        return
+    subprocess.check_call(['make', '-C', _HERE, 'all'], stdout=subprocess.DEVNULL)
+
+
+def load(variant='contract'):
+    if variant in _libs:
+        return _libs[variant]
+    name = {'contract': 'liboracle.so', 'libm': 'liboracle_libm.so'}[variant]
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        build()
+    lib = ctypes.CDLL(path)
+    lib.oracle_variant.restype = ctypes.c_char_p
+    assert lib.oracle_variant().decode() == variant
+    lib.oracle_propagate.restype = c_int32
+    lib.oracle_propagate.argtypes = [POINTER(_abi.GeometryDesc), POINTER(_abi.PhotonArrays), c_uint64, _abi.Rng,
+                                     c_int32, c_int32, c_int32, c_int32, POINTER(_abi.PropagateStats)]
+    lib.oracle_distance_to_mesh.restype = c_int32
+    lib.oracle_distance_to_mesh.argtypes = [POINTER(_abi.GeometryDesc), c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            POINTER(_abi.PropagateStats)]
+    lib.oracle_generate_bomb.restype = c_int32
+    lib.oracle_generate_bomb.argtypes = [POINTER(_abi.PhotonArrays), c_uint64, c_uint64, c_uint64, POINTER(c_float),
+                                         c_float, c_float]
+    lib.oracle_math.restype = c_int32
+    lib.oracle_math.argtypes = [c_int32, c_uint64, c_void_p, c_void_p, c_void_p]
+    lib.oracle_philox.restype = None
+    lib.oracle_philox.argtypes = [c_void_p, c_void_p, c_void_p]
+    lib.oracle_uniform_stream.restype = None
+    lib.oracle_uniform_stream.argtypes = [c_uint64, c_uint64, c_uint32, c_uint32, c_void_p]
+    lib.oracle_single.restype = c_int32
+    lib.oracle_single.argtypes = [POINTER(_abi.GeometryDesc), POINTER(_abi.PhotonArrays), _abi.Rng, c_int32,
+                                  POINTER(c_float), c_float, c_float, c_float, c_float, c_int32, c_int32, c_float,
+                                  c_int32, c_int32]
+    _libs[variant] = lib
+    return lib
+
+
+class HostPhotons(object):
+    """Writable host copies of the ten photon arrays + the ctypes struct pointing at them."""
+    FIELDS = (('pos', np.float32), ('dir', np.float32), ('pol', np.float32), ('wavelengths', np.float32),
+              ('t', np.float32), ('flags', np.uint32), ('last_hit_triangles', np.int32), ('weights', np.float32),
+              ('evidx', np.uint32))
+
+    def __init__(self, photons=None, n=None, rng_counters=None):
+        if photons is not None:
+            n = len(photons)
+            for name, dtype in self.FIELDS:
+                setattr(self, name, np.array(getattr(photons, name), dtype=dtype, order='C', copy=True))
+        else:
+            for name, dtype in self.FIELDS:
+                shape = (n, 3) if name in ('pos', 'dir', 'pol') else (n,)
+                setattr(self, name, np.zeros(shape, dtype=dtype))
+        self.rng_counters = np.zeros(n, dtype=np.uint32) if rng_counters is None \
+            else np.array(rng_counters, dtype=np.uint32, copy=True)
+        self.n = n
+        self.struct = _abi.PhotonArrays()
+        for name, _ in self.FIELDS:
+            setattr(self.struct, name, getattr(self, name).ctypes.data)
+        self.struct.rng_counters = self.rng_counters.ctypes.data
+
+    def photons(self):
+        return event.Photons(self.pos, self.dir, self.pol, self.wavelengths, self.t, self.last_hit_triangles,
+                             self.flags, self.weights, self.evidx)
+
+
+def propagate(packed, photons, seed, photon_id_base=0, max_steps=10, use_weights=False, scatter_first=0,
+              rng_counters=None, nthreads=1, variant='contract'):
+    """Run the oracle on ``photons`` (event.Photons).  Returns (Photons, rng_counters, stats dict)."""
+    lib = load(variant)
+    hp = HostPhotons(photons, rng_counters=rng_counters)
+    stats = _abi.PropagateStats()
+    rc = lib.oracle_propagate(ctypes.byref(packed.desc), ctypes.byref(hp.struct), hp.n, _abi.Rng(int(seed), int(photon_id_base)),
+                              int(max_steps), int(bool(use_weights)), int(scatter_first), int(nthreads), ctypes.byref(stats))
+    if rc != 0:
+        raise RuntimeError('oracle_propagate failed (%d)' % rc)
+    return hp.photons(), hp.rng_counters, stats.as_dict()
+
+
+def distance_to_mesh(packed, origins, directions, variant='contract'):
+    """(distance, triangle) for a ray bundle; misses give distance nan-filled here and triangle -1."""
+    lib = load(variant)
+    o = np.ascontiguousarray(origins, dtype=np.float32)
+    d = np.ascontiguousarray(directions, dtype=np.float32)
+    n = len(o)
+    dist = np.full(n, np.nan, dtype=np.float32)
+    tri = np.empty(n, dtype=np.int32)
+    stats = _abi.PropagateStats()
+    lib.oracle_distance_to_mesh(ctypes.byref(packed.desc), n, o.ctypes.data, d.ctypes.data, dist.ctypes.data,
+                                tri.ctypes.data, ctypes.byref(stats))
+    return dist, tri, stats.as_dict()
+
+
+def generate_bomb(n, seed, id_base=0, pos=(0, 0, 0), wavelength_lo=400.0, wavelength_hi=0.0, variant='contract'):
+    lib = load(variant)
+    hp = HostPhotons(n=n)
+    p = (c_float * 3)(*[float(x) for x in pos])
+    lib.oracle_generate_bomb(ctypes.byref(hp.struct), n, int(seed), int(id_base), p, float(wavelength_lo), float(wavelength_hi))
+    return hp.photons()
+
+
+def math_fn(fn, x, y=None, variant='contract'):
+    names = {'log': 0, 'exp': 1, 'sin': 2, 'cos': 3, 'tan': 4, 'asin': 5, 'acos': 6, 'atan2': 7, 'sqrt': 8, 'uniform': 9}
+    lib = load(variant)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = x if y is None else np.ascontiguousarray(y, dtype=np.float32)
+    out = np.empty_like(x)
+    rc = lib.oracle_math(names[fn], x.size, x.ctypes.data, y.ctypes.data, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def philox(counter, key):
+    lib = load()
+    c = np.array(counter, dtype=np.uint32)
+    k = np.array(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib.oracle_philox(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out
+
+
+def uniform_stream(seed, photon_id, n, start=0):
+    lib = load()
+    out = np.empty(n, dtype=np.float32)
+    lib.oracle_uniform_stream(int(seed), int(photon_id), int(start), int(n), out.ctypes.data)
+    return out

@@ -1,0 +1,269 @@
+"""Parity of the HIP engine with the CPU oracle, through the C ABI, on a real MI355X.
+
+Bar: history flags, hit triangle ids, draw counters and every float field BIT-EXACT against
+the contract-math oracle (both sides execute the arithmetic of include/chroma_math.h); the
+north star's looser float tolerance (1e-5 relative) is what separates the contract oracle from
+the libm oracle, checked on the CPU in tests/test_oracle.py.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from chroma_amd import event
+from chroma_amd.event import Photons
+from conftest import make_box_geometry, make_stress_geometry, bomb
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ('flags', 'last_hit_triangles', 'pos', 'dir', 'pol', 't', 'wavelengths', 'weights', 'evidx')
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    from chroma_amd import gpu as g
+    ctx = g.create_cuda_context(0)
+    yield g
+    ctx.pop()
+
+
+def assert_bit_exact(got, want, what=''):
+    for name in FIELDS:
+        a, b = getattr(got, name), getattr(want, name)
+        same = (a.view(np.uint32) == b.view(np.uint32)) if a.dtype == np.float32 else (a == b)
+        assert same.all(), '%s: %s differs for %d of %d photons (first at %s)' % (
+            what, name, np.count_nonzero(~same.reshape(len(a), -1).all(axis=1)), len(a), np.argwhere(~same)[0])
+
+
+def run_both(gpu, oracle_mod, geometry, photons, seed=12345, max_steps=100, **kw):
+    from chroma_amd.gpu.geometry import pack_geometry
+    gg = gpu.GPUDetector(geometry) if hasattr(geometry, 'num_channels') else gpu.GPUGeometry(geometry)
+    rng_states = gpu.get_rng_states(64 * 1024, seed=seed)
+    gp = gpu.GPUPhotons(photons)
+    stats = {}
+    gpu.get_context().set_counting(True)
+    gp.propagate(gg, rng_states, max_steps=max_steps, stats=stats, **kw)
+    gpu.get_context().set_counting(False)
+    got = gp.get()
+    want, counters, ostats = oracle_mod.propagate(pack_geometry(geometry), photons, seed=seed, max_steps=max_steps,
+                                                  nthreads=8, **kw)
+    return gg, gp, got, want, counters, stats, ostats
+
+
+def test_tiny_detector_full_histories(gpu, oracle_mod, tiny_geometry):
+    """demo.tiny(), 1e4 isotropic 400 nm photons from the centre."""
+    ph = oracle_mod.generate_bomb(10000, seed=20240502)
+    gg, gp, got, want, counters, stats, ostats = run_both(gpu, oracle_mod, tiny_geometry, ph)
+    assert_bit_exact(got, want, 'tiny')
+    assert np.array_equal(gp.rng_counters.get(), counters)
+    # same traversal: identical visit counts (the roofline's algorithmic bytes come from these)
+    for k in ('photon_steps', 'nodes_visited', 'triangles_tested'):
+        assert stats[k] == ostats[k], k
+    assert (got.flags & event.TERMINAL_MASK != 0).all()
+    assert 50 < np.count_nonzero(got.flags & event.SURFACE_DETECT) < 1000
+
+
+def test_large_batch_uses_per_step_launches(gpu, oracle_mod, tiny_geometry):
+    """> 8192 survivors: one step per launch with queue compaction (photon.py:225-252)."""
+    ph = bomb(60000, 3, wavelength=400.0, wavelength_hi=800.0)
+    gg, gp, got, want, counters, stats, ostats = run_both(gpu, oracle_mod, tiny_geometry, ph, max_steps=30)
+    assert_bit_exact(got, want, 'tiny 60k')
+    assert stats['launches'] == ostats['launches'] and stats['launches'] >= 2
+    assert stats['nodes_visited'] == ostats['nodes_visited']
+
+
+def test_every_surface_model_and_bulk_reemission(gpu, oracle_mod):
+    """BASELINE.md C5 in miniature: scintillator + thin film + WLS + dichroic + default surface."""
+    geo = make_stress_geometry()
+    ph = bomb(40000, 6, wavelength=350.0)
+    gg, gp, got, want, counters, stats, ostats = run_both(gpu, oracle_mod, geo, ph, seed=11)
+    assert_bit_exact(got, want, 'stress')
+    assert np.array_equal(gp.rng_counters.get(), counters)
+    assert int(np.bitwise_or.reduce(got.flags)) & 0x3FE == 0x3FE
+    assert (got.flags & event.NAN_ABORT).sum() == 0
+
+
+@pytest.mark.parametrize('use_weights,scatter_first', [(True, 0), (True, 1), (False, 1), (False, -1)])
+def test_weights_and_forced_scatter(gpu, oracle_mod, use_weights, scatter_first):
+    geo = make_box_geometry(100.0)
+    ph = bomb(20000, 8, wavelength=400.0)
+    gg, gp, got, want, counters, stats, ostats = run_both(gpu, oracle_mod, geo, ph, seed=5, max_steps=5,
+                                                          use_weights=use_weights, scatter_first=scatter_first)
+    assert_bit_exact(got, want, 'weights=%s scatter_first=%d' % (use_weights, scatter_first))
+
+
+def test_edge_inputs(gpu, oracle_mod, tiny_geometry):
+    gg = gpu.GPUDetector(tiny_geometry)
+    rng_states = gpu.get_rng_states(64, seed=1)
+    # empty batch
+    gp = gpu.GPUPhotons(Photons())
+    gp.propagate(gg, rng_states)
+    assert len(gp.get()) == 0 and len(gp.get_flat_hits(gg)) == 0
+    # one photon; already-terminal photons are left untouched (propagate.cu:258)
+    ph = bomb(5, 1)
+    ph.flags[:] = [0, event.BULK_ABSORB, 0, event.NO_HIT, event.SURFACE_DETECT]
+    ph.dir[1] *= 3.0                                      # not re-normalised for terminal photons
+    gp = gpu.GPUPhotons(ph)
+    gp.propagate(gg, rng_states, max_steps=10)
+    out = gp.get()
+    assert np.array_equal(out.dir[1], ph.dir[1]) and out.flags[1] == event.BULK_ABSORB
+    assert out.flags[0] & event.TERMINAL_MASK and out.flags[2] & event.TERMINAL_MASK
+    # NaN input -> NO_HIT | NAN_ABORT (propagate.cu:270-273)
+    ph = bomb(4, 2)
+    ph.pos[2, 1] = np.nan
+    gp = gpu.GPUPhotons(ph)
+    gp.propagate(gg, rng_states, max_steps=3)
+    assert gp.get().flags[2] == (event.NO_HIT | event.NAN_ABORT)
+    # photons outside the world pointing away: NO_HIT
+    ph = Photons(np.full((3, 3), 1e6), np.tile([1.0, 0, 0], (3, 1)), np.tile([0, 1.0, 0], (3, 1)), np.full(3, 400.0))
+    gp = gpu.GPUPhotons(ph)
+    gp.propagate(gg, rng_states, max_steps=3)
+    assert (gp.get().flags == event.NO_HIT).all()
+
+
+def test_repeated_propagate_single_steps(gpu, oracle_mod):
+    """Re-entrancy: 6 calls of max_steps=1 == oracle driven the same way (counters carried over)."""
+    from chroma_amd.gpu.geometry import pack_geometry
+    geo = make_stress_geometry()
+    pk = pack_geometry(geo)
+    ph = bomb(3000, 9, wavelength=350.0)
+    gg = gpu.GPUDetector(geo)
+    rng_states = gpu.get_rng_states(64, seed=21)
+    gp = gpu.GPUPhotons(ph)
+    cur, ctr = ph, None
+    for _ in range(6):
+        gp.propagate(gg, rng_states, max_steps=1)
+        cur, ctr, _ = oracle_mod.propagate(pk, cur, seed=21, max_steps=1, rng_counters=ctr)
+    assert_bit_exact(gp.get(), cur, 'single steps')
+    assert np.array_equal(gp.rng_counters.get(), ctr)
+
+
+def test_distance_to_mesh_vs_oracle(gpu, oracle_mod, tiny_geometry, tiny_packed):
+    from chroma_amd.gpu.tools import to_gpu, GPUArray
+    from chroma_amd.tools import from_film
+    rng = np.random.default_rng(4)
+    n = 50000
+    o = rng.uniform(-1500, 1500, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:6] = [[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]]      # 1/d = inf paths
+    o[:6] = 0
+    gg = gpu.GPUDetector(tiny_geometry)
+    ctx = gpu.get_context()
+    dist = GPUArray(n, np.float32, ctx).fill(np.float32(np.nan))
+    tri = GPUArray(n, np.int32, ctx)
+    from chroma_amd import _lib
+    _lib.check(ctx._lib.chroma_distance_to_mesh(ctx.handle, gg.handle, n, to_gpu(o.reshape(-1), ctx).ptr,
+                                                to_gpu(d.reshape(-1), ctx).ptr, dist.ptr, tri.ptr))
+    wd, wt, _ = oracle_mod.distance_to_mesh(tiny_packed, o, d)
+    gd, gt = dist.get(), tri.get()
+    assert np.array_equal(gt, wt)
+    assert np.array_equal(gd.view(np.uint32), wd.view(np.uint32))
+    assert (gt >= 0).mean() > 0.9
+
+
+def test_flat_hits_select_duplicate(gpu, oracle_mod, tiny_geometry):
+    ph = oracle_mod.generate_bomb(20000, seed=77)
+    gg = gpu.GPUDetector(tiny_geometry)
+    rng_states = gpu.get_rng_states(64, seed=3)
+    gp = gpu.GPUPhotons(ph)
+    gp.propagate(gg, rng_states, max_steps=100)
+    end = gp.get()
+    # reference semantics of count/copy_photon_hits (propagate.cu:147-214), by hand
+    det = (end.flags & event.SURFACE_DETECT) != 0
+    tri = end.last_hit_triangles
+    chan = np.full(len(end), -1)
+    ok = det & (tri > -1)
+    chan[ok] = tiny_geometry.solid_id_to_channel_index[tiny_geometry.solid_id[tri[ok]]]
+    expect = np.flatnonzero(chan >= 0)
+    hits = gp.get_flat_hits(gg)
+    assert len(hits) == len(expect) > 0
+    # order is unspecified (atomics): compare as sets keyed by position+time
+    key = lambda p, idx: sorted(zip(p.pos[idx, 0].tolist(), p.pos[idx, 1].tolist(), p.t[idx].tolist()))
+    assert key(hits, np.arange(len(hits))) == key(end, expect)
+    lookup = {(x, y, t): c for x, y, t, c in zip(end.pos[expect, 0].tolist(), end.pos[expect, 1].tolist(), end.t[expect].tolist(), chan[expect].tolist())}
+    assert all(lookup[(x, y, t)] == c for x, y, t, c in zip(hits.pos[:, 0].tolist(), hits.pos[:, 1].tolist(), hits.t.tolist(), hits.channel.tolist()))
+    hitmap = gp.get_hits(gg)
+    assert sum(len(v) for v in hitmap.values()) == len(hits)
+    # per-channel reduction
+    counts, earliest = gp.channel_hits(gg)
+    assert np.array_equal(counts.get(), np.bincount(chan[expect], minlength=gg.nchannels).astype(np.uint32))
+    e = earliest.get().view(np.float32)
+    for c in np.unique(chan[expect])[:10]:
+        assert e[c] == end.t[expect][chan[expect] == c].min()
+    # select
+    sel = gp.select(event.SURFACE_ABSORB).get()
+    assert len(sel) == np.count_nonzero(end.flags & event.SURFACE_ABSORB)
+    assert sorted(sel.t.tolist()) == sorted(end.t[(end.flags & event.SURFACE_ABSORB) != 0].tolist())
+    # ncopies: clones get the same inputs but their own random streams
+    small = ph[:500]
+    gp2 = gpu.GPUPhotons(small, ncopies=3)
+    assert len(gp2) == 1500
+    before = gp2.get()
+    for k in range(3):
+        assert np.array_equal(before.dir[500 * k:500 * (k + 1)], small.dir)
+    gp2.propagate(gg, rng_states, max_steps=20)
+    after = gp2.get()
+    assert not np.array_equal(after.flags[:500], after.flags[500:1000]) or not np.array_equal(after.t[:500], after.t[500:1000])
+    assert len(list(gp2.iterate_copies())) == 3
+
+
+def test_tracking_mode(gpu, oracle_mod):
+    geo = make_stress_geometry()
+    ph = bomb(300, 12, wavelength=350.0)
+    gg = gpu.GPUDetector(geo)
+    rng_states = gpu.get_rng_states(64, seed=2)
+    gp = gpu.GPUPhotons(ph)
+    ids, steps = gp.propagate(gg, rng_states, max_steps=8, track=True)
+    assert len(ids) == len(steps) and len(ids[0]) == 300
+    assert all(len(i) == len(s) for i, s in zip(ids, steps))
+    assert len(ids[-1]) <= len(ids[0])
+
+
+def test_simulation_api_ports_of_reference_tests(gpu):
+    """Ports of test/test_propagation.py and test/test_rayleigh.py through Simulation."""
+    from chroma_amd.sim import Simulation
+    from chroma_amd.geometry import Geometry, Solid, vacuum
+    from chroma_amd.make import box
+    from chroma_amd.demo.optics import water
+    from scipy import stats as sstats
+    cube = Geometry(vacuum)
+    cube.add_solid(Solid(box(100, 100, 100), vacuum, vacuum))
+    sim = Simulation(cube, geant4_processes=0, seed=1)
+    n = 10000
+    rng = np.random.default_rng(0)
+    d = np.zeros((n, 3)); axis = rng.integers(0, 3, n); d[np.arange(n), axis] = rng.choice([-1.0, 1.0], n)
+    pol = np.zeros((n, 3)); ang = rng.uniform(0, 2 * np.pi, n)
+    pol[np.arange(n), (axis + 1) % 3] = np.cos(ang); pol[np.arange(n), (axis + 2) % 3] = np.sin(ang)
+    photons = Photons(np.zeros((n, 3)), d, pol, np.full(n, 400.0))
+    end = next(sim.simulate([photons], keep_photons_end=True, max_steps=1)).photons_end
+    for a in (end.pos, end.dir, end.pol, end.t, end.wavelengths):
+        assert not np.isnan(a).any()
+    end = next(sim.simulate([photons], keep_photons_end=True, max_steps=10)).photons_end
+    assert (end.flags & event.NAN_ABORT).sum() == 0
+
+    wbox = Geometry(water)
+    wbox.add_solid(Solid(box(100, 100, 100), water, water))
+    sim = Simulation(wbox, geant4_processes=0, seed=2)
+    n = 2000000
+    photons = Photons(np.zeros((n, 3)), np.tile([0.0, 0.0, 1.0], (n, 1)), np.tile([1.0, 0.0, 0.0], (n, 1)), np.full(n, 400.0))
+    end = next(sim.simulate([photons], keep_photons_end=True, max_steps=1)).photons_end
+    m = (end.flags & event.RAYLEIGH_SCATTER) != 0
+    assert m.sum() > 1000
+    theta = np.arccos(np.clip(end.dir[m, 2], -1, 1))
+    hist, edges = np.histogram(theta, bins=20, range=(0, np.pi))
+    cdf = lambda t: (4.0 / 3.0 - np.cos(t) - np.cos(t) ** 3 / 3.0) / (8.0 / 3.0)
+    expect = m.sum() * np.diff(cdf(edges))
+    assert sstats.chi2.sf(((hist - expect) ** 2 / expect).sum(), len(hist) - 1) > 1e-3
+
+
+def test_simulation_batching_and_per_event_split(gpu, tiny_geometry):
+    from chroma_amd.sim import Simulation
+    sim = Simulation(tiny_geometry, geant4_processes=0, seed=5)
+    events = [bomb(n, 100 + n) for n in (700, 1500, 300)]
+    out = list(sim.simulate(events, keep_photons_end=True, photons_per_batch=2000, max_steps=50))
+    assert [len(ev.photons_end) for ev in out] == [700, 1500, 300] and [ev.id for ev in out] == [0, 1, 2]
+    for ev in out:
+        det = (ev.photons_end.flags & event.SURFACE_DETECT) != 0
+        assert len(ev.flat_hits) <= det.sum()
+        assert sum(len(v) for v in ev.hits.values()) == len(ev.flat_hits)
+        assert (ev.flat_hits.flags & event.SURFACE_DETECT != 0).all()

@@ -1,0 +1,140 @@
+"""The CPU oracle on its own: the reference's statistical tests restated (the only tests the
+reference holds for the physics), determinism, re-entrancy, and the libm cross-check."""
+import numpy as np
+import pytest
+from scipy import stats
+
+from chroma_amd import event
+from chroma_amd.event import Photons
+from chroma_amd.gpu.geometry import pack_geometry
+from conftest import make_box_geometry, make_stress_geometry, bomb
+
+
+@pytest.fixture(scope='module')
+def water_box():
+    return pack_geometry(make_box_geometry(100.0))
+
+
+@pytest.fixture(scope='module')
+def vacuum_box():
+    from chroma_amd.geometry import vacuum
+    return pack_geometry(make_box_geometry(100.0, material=vacuum))
+
+
+def axis_photons(n, rng):
+    """test/test_propagation.py:27-35: photons from the centre along +-x, +-y, +-z with random
+    transverse polarisation."""
+    d = np.zeros((n, 3))
+    axis = rng.integers(0, 3, n)
+    d[np.arange(n), axis] = rng.choice([-1.0, 1.0], n)
+    pol = np.zeros((n, 3))
+    ang = rng.uniform(0, 2 * np.pi, n)
+    pol[np.arange(n), (axis + 1) % 3] = np.cos(ang)
+    pol[np.arange(n), (axis + 2) % 3] = np.sin(ang)
+    return Photons(np.zeros((n, 3)), d, pol, np.full(n, 400.0))
+
+
+def test_propagation_no_nan_no_abort(oracle_mod, vacuum_box):
+    """Restates test/test_propagation.py:12-57 (testAbort / no NaN)."""
+    rng = np.random.default_rng(0)
+    ph = axis_photons(10000, rng)
+    out, _, _ = oracle_mod.propagate(vacuum_box, ph, seed=1, max_steps=1)
+    for a in (out.pos, out.dir, out.pol, out.t, out.wavelengths):
+        assert not np.isnan(a).any()
+    out, _, _ = oracle_mod.propagate(vacuum_box, ph, seed=1, max_steps=10)
+    assert (out.flags & event.NAN_ABORT).sum() == 0
+
+
+def test_rayleigh_angular_distribution(oracle_mod, water_box):
+    """Restates test/test_rayleigh.py:13-54 with SciPy instead of ROOT: the angle between the
+    initial and final direction of Rayleigh-scattered photons follows (1 + cos^2) sin."""
+    n = 100000
+    ph = Photons(np.zeros((n, 3)), np.tile([0.0, 0.0, 1.0], (n, 1)), np.tile([1.0, 0.0, 0.0], (n, 1)), np.full(n, 400.0))
+    # water scatters once per ~40 m, so a 100 mm box gives only ~80 natural scatters per 1e5
+    # photons (what the reference's test fits); scatter_first=1 forces one for every photon
+    out, _, _ = oracle_mod.propagate(water_box, ph, seed=3, max_steps=1, scatter_first=1)
+    m = (out.flags & event.RAYLEIGH_SCATTER) != 0
+    assert m.sum() > 0.4 * n      # the forced-scatter loop gives up after 1000 redraws (photon.h:211)
+    cos_t = np.clip(out.dir[m] @ np.array([0.0, 0.0, 1.0]), -1, 1)
+    theta = np.arccos(cos_t)
+    hist, edges = np.histogram(theta, bins=25, range=(0, np.pi))
+    cdf = lambda t: (4.0 / 3.0 - np.cos(t) - np.cos(t) ** 3 / 3.0) / (8.0 / 3.0)     # integral of (1+cos^2) sin
+    expect = m.sum() * np.diff(cdf(edges))
+    chi2 = ((hist - expect) ** 2 / expect).sum()
+    assert stats.chi2.sf(chi2, len(hist) - 1) > 1e-3
+    # polarisation stays transverse and unit
+    assert np.allclose(np.linalg.norm(out.pol[m], axis=1), 1, atol=1e-5)
+    assert np.abs((out.pol[m] * out.dir[m]).sum(1)).max() < 1e-4
+
+
+def test_deterministic_and_thread_independent(oracle_mod, tiny_packed):
+    ph = oracle_mod.generate_bomb(3000, seed=9)
+    a, ca, sa = oracle_mod.propagate(tiny_packed, ph, seed=12345, max_steps=100, nthreads=1)
+    b, cb, sb = oracle_mod.propagate(tiny_packed, ph, seed=12345, max_steps=100, nthreads=4)
+    for name in ('pos', 'dir', 'pol', 't', 'wavelengths', 'flags', 'last_hit_triangles', 'weights'):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.array_equal(ca, cb) and sa['nodes_visited'] == sb['nodes_visited']
+    # the photon-id base selects the stream: shifting ids == shifting photons
+    c, _, _ = oracle_mod.propagate(tiny_packed, ph[1000:2000], seed=12345, photon_id_base=1000, max_steps=100)
+    assert np.array_equal(c.flags, a.flags[1000:2000]) and np.array_equal(c.pos, a.pos[1000:2000])
+    d, _, _ = oracle_mod.propagate(tiny_packed, ph, seed=54321, max_steps=100)
+    assert not np.array_equal(d.flags, a.flags)
+
+
+def test_single_stepping_equals_one_call(oracle_mod):
+    """propagate() may be called repeatedly (chroma/gpu/photon.py:199-200): ten calls of one
+    step give the histories of one call of ten steps, thanks to the per-photon draw counter.
+    Floats agree to rounding only: every call re-normalises dir/pol on load (propagate.cu:248,250)."""
+    pk = pack_geometry(make_stress_geometry())
+    ph = bomb(4000, 5, wavelength=350.0)
+    full, cfull, _ = oracle_mod.propagate(pk, ph, seed=7, max_steps=10)
+    cur, ctr = ph, None
+    for _ in range(10):
+        cur, ctr, _ = oracle_mod.propagate(pk, cur, seed=7, max_steps=1, rng_counters=ctr)
+    assert np.array_equal(cur.flags, full.flags) and np.array_equal(ctr, cfull)
+    assert np.allclose(cur.pos, full.pos, rtol=1e-5, atol=1e-3) and np.allclose(cur.t, full.t, rtol=1e-5, atol=1e-4)
+
+
+def test_every_physics_branch_is_reached(oracle_mod):
+    pk = pack_geometry(make_stress_geometry())
+    ph = bomb(60000, 6, wavelength=350.0)
+    out, _, st = oracle_mod.propagate(pk, ph, seed=11, max_steps=100, nthreads=4)
+    assert int(np.bitwise_or.reduce(out.flags)) & 0x3FE == 0x3FE        # bits 1..9 (the world box catches escapes)
+    assert (out.flags & event.NAN_ABORT).sum() == 0
+    assert len(np.unique(out.flags)) > 40
+    assert (out.flags & event.TERMINAL_MASK != 0).all()
+    re = (out.flags & (event.BULK_REEMIT | event.SURFACE_REEMIT)) != 0
+    assert out.wavelengths[re].mean() > 380                               # re-emission shifts to 400-500 nm
+    assert st['stack_overflows'] == 0
+
+
+def test_weights_and_scatter_first(oracle_mod, water_box):
+    ph = bomb(20000, 8, wavelength=400.0)
+    out, _, _ = oracle_mod.propagate(water_box, ph, seed=5, max_steps=5, use_weights=True, scatter_first=1)
+    assert ((out.flags & event.RAYLEIGH_SCATTER) != 0).mean() > 0.4       # forced scatter (1000-redraw cap)
+    assert (out.weights < 1).all() and (out.weights > 0).all()
+    assert (out.flags & event.BULK_ABSORB).sum() == 0                      # weights mode never absorbs in the bulk
+    out2, _, _ = oracle_mod.propagate(water_box, ph, seed=5, max_steps=1, scatter_first=-1)
+    assert ((out2.flags & event.RAYLEIGH_SCATTER) != 0).sum() == 0        # scatter prevented
+
+
+def test_libm_build_agrees(oracle_mod, tiny_packed):
+    """Independent check that nothing physical hinges on the contract's polynomials."""
+    ph = oracle_mod.generate_bomb(20000, seed=4)
+    a, _, _ = oracle_mod.propagate(tiny_packed, ph, seed=12345, max_steps=100, nthreads=4)
+    b, _, _ = oracle_mod.propagate(tiny_packed, ph, seed=12345, max_steps=100, nthreads=4, variant='libm')
+    same = a.flags == b.flags
+    assert same.mean() > 0.999
+    assert np.array_equal(a.last_hit_triangles[same], b.last_hit_triangles[same])
+    scale = np.maximum(np.linalg.norm(a.pos[same], axis=1), 1.0)[:, None]
+    assert (np.abs(a.pos[same] - b.pos[same]) / scale).max() < 1e-5
+    assert np.allclose(a.t[same], b.t[same], rtol=1e-5, atol=1e-5)
+
+
+def test_ray_cast_basics(oracle_mod, vacuum_box):
+    o = np.zeros((6, 3), dtype=np.float32)
+    d = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float32)
+    dist, tri, _ = oracle_mod.distance_to_mesh(vacuum_box, o, d)         # axis-aligned: 1/d = inf on two axes
+    assert np.allclose(dist, 50.0) and (tri >= 0).all()
+    dist, tri, _ = oracle_mod.distance_to_mesh(vacuum_box, o + np.float32(200.0), d[:1])   # outside, pointing away
+    assert tri[0] == -1 and np.isnan(dist[0])
