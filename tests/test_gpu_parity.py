@@ -152,8 +152,8 @@ def test_distance_to_mesh_vs_oracle(gpu, oracle_mod, tiny_geometry, tiny_packed)
     dist = GPUArray(n, np.float32, ctx).fill(np.float32(np.nan))
     tri = GPUArray(n, np.int32, ctx)
     from chroma_amd import _lib
-    _lib.check(ctx._lib.chroma_distance_to_mesh(ctx.handle, gg.handle, n, to_gpu(o.reshape(-1), ctx).ptr,
-                                                to_gpu(d.reshape(-1), ctx).ptr, dist.ptr, tri.ptr))
+    d_o, d_d = to_gpu(o.reshape(-1), ctx), to_gpu(d.reshape(-1), ctx)      # keep the device arrays alive
+    _lib.check(ctx._lib.chroma_distance_to_mesh(ctx.handle, gg.handle, n, d_o.ptr, d_d.ptr, dist.ptr, tri.ptr))
     wd, wt, _ = oracle_mod.distance_to_mesh(tiny_packed, o, d)
     gd, gt = dist.get(), tri.get()
     assert np.array_equal(gt, wt)

@@ -52,8 +52,8 @@ def test_engine_and_oracle_match_reference_traversal(oracle_mod, tiny_geometry, 
     gg = gpu.GPUDetector(tiny_geometry)
     dist = GPUArray(n, np.float32, ctx).fill(np.float32(np.nan))
     tri = GPUArray(n, np.int32, ctx)
-    _lib.check(ctx._lib.chroma_distance_to_mesh(ctx.handle, gg.handle, n, to_gpu(o.reshape(-1), ctx).ptr,
-                                                to_gpu(d.reshape(-1), ctx).ptr, dist.ptr, tri.ptr))
+    d_o, d_d = to_gpu(o.reshape(-1), ctx), to_gpu(d.reshape(-1), ctx)      # keep the device arrays alive
+    _lib.check(ctx._lib.chroma_distance_to_mesh(ctx.handle, gg.handle, n, d_o.ptr, d_d.ptr, dist.ptr, tri.ptr))
     assert np.array_equal(tri.get(), rtri)
     assert np.array_equal(dist.get().view(np.uint32), rdist.view(np.uint32))
     assert (rtri >= 0).mean() > 0.9
