@@ -163,12 +163,17 @@ def main():
     ctx.synchronize()
 
     for i in range(args.warmup):
+        t_step = time.perf_counter()
         run_step(batches[i], False, {})
+        log('  warmup %d: %.1f ms wall' % (i, 1e3 * (time.perf_counter() - t_step)))
     sync_all()
     stats = {}
     t_start = time.perf_counter()
     for i in range(args.warmup, nbatches):
+        t_step = time.perf_counter()
+        k0 = stats.get('kernel_ms', 0.0)
         run_step(batches[i], True, stats)
+        log('  step %d: %.1f ms wall, %.1f ms in propagate kernels' % (i - args.warmup, 1e3 * (time.perf_counter() - t_step), stats['kernel_ms'] - k0))
     sync_all()
     elapsed = time.perf_counter() - t_start
     if world > 1:

@@ -44,6 +44,9 @@ struct chroma_ctx {
     // queue ping-pong buffers for chroma_propagate (n+1 words each)
     uint32_t *queue_a = nullptr, *queue_b = nullptr;
     size_t queue_capacity = 0;
+    // (triangle, distance) per queue slot handed from k_raycast to k_physics
+    int32_t *hit_triangle = nullptr;
+    float *hit_distance = nullptr;
     // small device scratch: [0..3] DeviceCounters, then misc words
     DeviceCounters *d_counters = nullptr;
     uint32_t *d_words = nullptr;        // 16 words
@@ -66,6 +69,7 @@ struct chroma_geometry {
 // kernels
 // ---------------------------------------------------------------------------------------------------
 #define PROP_BLOCK 64
+#define STACK_LDS 24      // traversal stack entries kept in LDS (6 KB per wave); deeper ones spill to scratch
 
 // propagate (chroma/cuda/propagate.cu:217-319)
 template <int STACK_N, bool COUNT>
@@ -112,17 +116,9 @@ k_propagate(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint
                 fill_state<STACK_N, PROP_BLOCK, COUNT>(s, p, g, stack, cnt);
                 if (p.last_hit_triangle == -1) break;
 
-                int command = propagate_to_boundary(p, s, rng, g, use_weights != 0, scatter_first);
+                bool go_on = step_after_hit(p, s, rng, g, use_weights != 0, scatter_first);
                 scatter_first = 0;
-                if (command == CMD_BREAK) break;
-                if (command == CMD_CONTINUE) continue;
-
-                if (s.surface_index != -1) {
-                    command = propagate_at_surface(p, s, rng, g, use_weights != 0);
-                    if (command == CMD_BREAK) break;
-                    if (command == CMD_CONTINUE) continue;
-                }
-                propagate_at_boundary(p, s, rng);
+                if (!go_on) break;
             }
             pv.rng_counters[photon_id] = rng.counter;
             store3(pv.pos, photon_id, p.position);
@@ -154,6 +150,102 @@ k_propagate(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint
         }
         if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
     }
+}
+
+// ---- one step split in two launches (used while many photons are alive) ------------------------
+// The ray cast needs few registers and benefits from many resident waves; the physics needs many
+// registers and little time.  k_raycast writes (triangle, distance) per queue slot, k_physics
+// consumes them.  Together they perform exactly one iteration of the loop of k_propagate for every
+// queued photon, with identical arithmetic (both re-normalise dir/pol on load like propagate.cu:248,250).
+#define HIT_SKIP (-3)      // photon already terminal: untouched (propagate.cu:258)
+#define HIT_NAN  (-2)      // NaN guard fired (propagate.cu:270-273)
+
+template <int LDS_N, bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK) void
+k_raycast(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
+          int32_t *hit_triangle, float *hit_distance, DeviceCounters *counters)
+{
+    __shared__ uint32_t s_stack[LDS_N * PROP_BLOCK];
+    int id = blockIdx.x * PROP_BLOCK + threadIdx.x;
+    LaneCounters cnt = {0, 0, 0, 0};
+    if (id < nthreads) {
+        uint32_t photon_id = input_queue ? input_queue[first_photon + id] : (uint32_t)(first_photon + id);
+        int tri = HIT_SKIP;
+        float dist = 0.0f;
+        if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
+            v3 position = load3(pv.pos, photon_id);
+            v3 direction = load3(pv.dir, photon_id);
+            direction = direction / norm(direction);
+            if (cm_isnan(direction.x * direction.y * direction.z * position.x * position.y * position.z)) {
+                tri = HIT_NAN;
+            } else {
+                if (COUNT) cnt.steps++;
+                tri = intersect_mesh<LDS_N, PROP_BLOCK, COUNT>(g, position, direction, dist, pv.last_hit_triangles[photon_id],
+                                                               s_stack + threadIdx.x, cnt);
+            }
+        }
+        hit_triangle[first_photon + id] = tri;
+        hit_distance[first_photon + id] = dist;
+    }
+    unsigned long long ov = wave_sum_u64(cnt.overflows);
+    if (COUNT) {
+        unsigned long long st = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        if (lane_id() == 0) {
+            atomicAdd(&counters->photon_steps, st);
+            atomicAdd(&counters->nodes_visited, nd);
+            atomicAdd(&counters->triangles_tested, tr);
+        }
+    }
+    if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
+}
+
+__global__ __launch_bounds__(256) void
+k_physics(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue, uint32_t *output_queue,
+          const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base, int use_weights,
+          int scatter_first)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    bool alive = false;
+    uint32_t photon_id = 0;
+    if (id < nthreads) {
+        photon_id = input_queue ? input_queue[first_photon + id] : (uint32_t)(first_photon + id);
+        int tri = hit_triangle[first_photon + id];
+        if (tri != HIT_SKIP) {
+            Photon p;
+            p.position = load3(pv.pos, photon_id);
+            p.direction = load3(pv.dir, photon_id);
+            p.direction = p.direction / norm(p.direction);
+            p.polarization = load3(pv.pol, photon_id);
+            p.polarization = p.polarization / norm(p.polarization);
+            p.wavelength = pv.wavelengths[photon_id];
+            p.time = pv.t[photon_id];
+            p.last_hit_triangle = pv.last_hit_triangles[photon_id];
+            p.history = pv.flags[photon_id];
+            p.weight = pv.weights[photon_id];
+            p.evidx = pv.evidx[photon_id];
+            cm_rng rng;
+            cm_rng_init(&rng, seed, id_base + photon_id, pv.rng_counters[photon_id]);
+            if (tri == HIT_NAN) {
+                p.history |= CHROMA_NO_HIT | CHROMA_NAN_ABORT;
+            } else {
+                State s;
+                apply_hit(s, p, g, tri, hit_distance[first_photon + id]);
+                if (tri != -1) step_after_hit(p, s, rng, g, use_weights != 0, scatter_first);
+            }
+            pv.rng_counters[photon_id] = rng.counter;
+            store3(pv.pos, photon_id, p.position);
+            store3(pv.dir, photon_id, p.direction);
+            store3(pv.pol, photon_id, p.polarization);
+            pv.wavelengths[photon_id] = p.wavelength;
+            pv.t[photon_id] = p.time;
+            pv.flags[photon_id] = p.history;
+            pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
+            pv.weights[photon_id] = p.weight;
+            pv.evidx[photon_id] = p.evidx;
+            alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
+        }
+    }
+    if (output_queue) wave_queue_append(output_queue, alive, photon_id);
 }
 
 // initial queue of GPUPhotons.propagate (chroma/gpu/photon.py:206-216): slot 0 unused counter,
@@ -366,7 +458,6 @@ static int check_photons(const chroma_photon_arrays *a, bool need_rng)
     return CHROMA_OK;
 }
 
-static const int STACK_VARIANTS[] = {32, 64, 128};
 
 template <bool COUNT>
 static int launch_propagate_t(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, int first, int nthreads,
@@ -378,10 +469,8 @@ static int launch_propagate_t(chroma_ctx *ctx, chroma_geometry *geom, PhotonView
 #define LAUNCH(N)                                                                                         \
     hipLaunchKernelGGL((k_propagate<N, COUNT>), grid, block, 0, ctx->stream, geom->view, pv, first, nthreads, \
                        in_q, out_q, rng.seed, rng.photon_id_base, max_steps, use_weights, scatter_first, ctx->d_counters)
-    if (need <= 32) LAUNCH(32);
-    else if (need <= 64) LAUNCH(64);
-    else if (need <= 128) LAUNCH(128);
-    else return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the 128 supported", need);
+    if (need <= STACK_LDS + STACK_SCRATCH) LAUNCH(STACK_LDS);
+    else return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
@@ -395,6 +484,27 @@ static int launch_propagate(chroma_ctx *ctx, chroma_geometry *geom, PhotonView p
     if (ctx->counting)
         return launch_propagate_t<true>(ctx, geom, pv, first, nthreads, in_q, out_q, rng, max_steps, use_weights, scatter_first);
     return launch_propagate_t<false>(ctx, geom, pv, first, nthreads, in_q, out_q, rng, max_steps, use_weights, scatter_first);
+}
+
+// one step for many photons: ray cast and physics as two launches
+static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, int nthreads, const uint32_t *in_q,
+                             uint32_t *out_q, chroma_rng rng, int use_weights, int scatter_first)
+{
+    if (nthreads <= 0) return CHROMA_OK;
+    uint32_t need = geom->stack_need;
+    if (need > STACK_LDS + STACK_SCRATCH)
+        return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
+    dim3 grid((unsigned)((nthreads + PROP_BLOCK - 1) / PROP_BLOCK)), block(PROP_BLOCK);
+    if (ctx->counting)
+        hipLaunchKernelGGL((k_raycast<STACK_LDS, true>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->d_counters);
+    else
+        hipLaunchKernelGGL((k_raycast<STACK_LDS, false>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->d_counters);
+    hipLaunchKernelGGL(k_physics, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream, geom->view, pv, 0, nthreads,
+                       in_q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
 }
 
 template <class T>
@@ -486,6 +596,8 @@ int chroma_shutdown(chroma_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     if (ctx->queue_a) hipFree(ctx->queue_a);
     if (ctx->queue_b) hipFree(ctx->queue_b);
+    if (ctx->hit_triangle) hipFree(ctx->hit_triangle);
+    if (ctx->hit_distance) hipFree(ctx->hit_distance);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_words);
     hipHostFree(ctx->h_words);
@@ -692,10 +804,10 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     v.nnodes = d->nnodes; v.ntriangles = d->ntriangles; v.nsolids = d->nsolids; v.nchannels = d->nchannels;
 
     g->stack_need = compute_stack_need(d->nodes, d->nnodes);
-    if (g->stack_need > 128) {
+    if (g->stack_need > STACK_LDS + STACK_SCRATCH) {
         uint32_t need = g->stack_need;
         chroma_geometry_destroy(g);
-        return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the 128 supported", need);
+        return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
     }
     *out = g;
     return CHROMA_OK;
@@ -860,8 +972,9 @@ int chroma_distance_to_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthr
     uint32_t need = geom->stack_need;
 #define LAUNCH(N, C) hipLaunchKernelGGL((k_distance_to_mesh<N, C>), grid, block, 0, ctx->stream, geom->view, nthreads, \
                                         d_origin, d_direction, d_distance, d_triangle, ctx->d_counters)
-    if (ctx->counting) { if (need <= 32) LAUNCH(32, true); else if (need <= 64) LAUNCH(64, true); else LAUNCH(128, true); }
-    else { if (need <= 32) LAUNCH(32, false); else if (need <= 64) LAUNCH(64, false); else LAUNCH(128, false); }
+    if (need > STACK_LDS + STACK_SCRATCH)
+        return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
+    if (ctx->counting) LAUNCH(STACK_LDS, true); else LAUNCH(STACK_LDS, false);
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
@@ -874,10 +987,15 @@ static int ensure_queues(chroma_ctx *ctx, size_t n)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->queue_a) hipFree(ctx->queue_a);
     if (ctx->queue_b) hipFree(ctx->queue_b);
+    if (ctx->hit_triangle) hipFree(ctx->hit_triangle);
+    if (ctx->hit_distance) hipFree(ctx->hit_distance);
     ctx->queue_a = ctx->queue_b = nullptr;
+    ctx->hit_triangle = nullptr; ctx->hit_distance = nullptr;
     ctx->queue_capacity = 0;
     HIP_TRY(hipMalloc((void **)&ctx->queue_a, (n + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->queue_b, (n + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->hit_triangle, (n + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->hit_distance, (n + 1) * sizeof(float)));
     ctx->queue_capacity = n + 1;
     return CHROMA_OK;
 }
@@ -931,7 +1049,10 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         // finish in one launch once few photons are left (chroma/gpu/photon.py:227-230)
         int nsteps = (n < (uint64_t)PROP_BLOCK * 16 * 8 || use_weights) ? (max_steps - step) : 1;
         if (time_kernels) HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-        rc = launch_propagate(ctx, geom, pv, 0, (int)n, in_q + 1, out_q, rng, nsteps, use_weights, scatter_first);
+        if (nsteps == 1)
+            rc = launch_split_step(ctx, geom, pv, (int)n, in_q + 1, out_q, rng, use_weights, scatter_first);
+        else
+            rc = launch_propagate(ctx, geom, pv, 0, (int)n, in_q + 1, out_q, rng, nsteps, use_weights, scatter_first);
         if (rc) return rc;
         launches++;
         if (time_kernels) {

@@ -72,8 +72,13 @@ __device__ inline bool intersect_triangle(v3 origin, v3 direction, v3 v0, v3 v1,
     return false;
 }
 
-// intersect_box (intersect.h:107-147) + the pruning rule of intersect_node (mesh.h:16-34)
-__device__ inline bool intersect_node(v3 noid, v3 inv_dir, v3 lower, v3 upper, float min_distance)
+// Slab test of intersect_box (intersect.h:107-147) for one child.  Returns tmin (the distance to
+// the box) or -1 when the ray misses it.  For an axis the ray is exactly parallel to (1/d = +-inf)
+// the reference skips the slab altogether (intersect.h:115,124,133), which makes such a ray walk
+// every box in its plane; here the parallel axis is a containment test instead: a box whose slab
+// does not contain the origin's coordinate cannot hold a triangle this ray hits (leaf boxes are
+// padded by one quantum, bvh.cu:181-185), so the hit found is the same while the walk stays short.
+__device__ inline float box_tmin(v3 origin, v3 noid, v3 inv_dir, v3 lower, v3 upper)
 {
     float tmin = 0.0f, tmax = cm_inff();
     float t0, t1;
@@ -82,33 +87,53 @@ __device__ inline bool intersect_node(v3 noid, v3 inv_dir, v3 lower, v3 upper, f
         t1 = upper.x * inv_dir.x + noid.x;
         tmin = cm_fmaxf(tmin, cm_fminf(t0, t1));
         tmax = cm_fminf(tmax, cm_fmaxf(t0, t1));
-    }
+    } else if (origin.x < lower.x || origin.x > upper.x) return -1.0f;
     if (cm_isfinite(inv_dir.y)) {
         t0 = lower.y * inv_dir.y + noid.y;
         t1 = upper.y * inv_dir.y + noid.y;
         tmin = cm_fmaxf(tmin, cm_fminf(t0, t1));
         tmax = cm_fminf(tmax, cm_fmaxf(t0, t1));
-    }
+    } else if (origin.y < lower.y || origin.y > upper.y) return -1.0f;
     if (cm_isfinite(inv_dir.z)) {
         t0 = lower.z * inv_dir.z + noid.z;
         t1 = upper.z * inv_dir.z + noid.z;
         tmin = cm_fmaxf(tmin, cm_fminf(t0, t1));
         tmax = cm_fminf(tmax, cm_fmaxf(t0, t1));
-    }
-    if (tmin > tmax) return false;
+    } else if (origin.z < lower.z || origin.z > upper.z) return -1.0f;
+    if (tmin > tmax) return -1.0f;
+    return tmin;
+}
+
+// pruning rule of intersect_node (mesh.h:16-34) given the box distance
+__device__ inline bool node_passes(float tmin, float min_distance)
+{
+    if (tmin < 0.0f) return false;
     if (min_distance < 0.0f) return true;
-    if (tmin > min_distance) return false;
-    return true;
+    return !(tmin > min_distance);
 }
 
 // ---- mesh.h ---------------------------------------------------------------------------------
-// intersect_mesh (mesh.h:42-118): depth-first walk over child ranges.  A stack entry is the
-// packed `w` word of a node (nchild<<28 | first_child).  `stack` points at this lane's column
-// of an LDS array laid out [entry][BLOCK]; STACK_N entries are available (the host checks the
-// tree's worst case against it before launching, chroma_geometry_stack_need).
-template <int STACK_N, int BLOCK, bool COUNT>
+// Traversal stack: a stack entry is the packed `w` word of a node (nchild<<28 | first_child),
+// exactly what the reference keeps in its two 1000-entry local arrays (mesh.h:58-59).  The
+// first LDS_N entries live in LDS ([entry][lane]: one bank per lane), deeper ones -- rare: the
+// observed depth is ~20 -- in a per-lane scratch array, so LDS use stays at LDS_N*256 B per wave.
+#define STACK_SCRATCH 104
+template <int LDS_N, int BLOCK>
+struct TravStack {
+    uint32_t *lds;                       // this lane's column
+    uint32_t spill[STACK_SCRATCH];
+    __device__ inline void put(int i, uint32_t w) { if (i < LDS_N) lds[i * BLOCK] = w; else spill[i - LDS_N] = w; }
+    __device__ inline uint32_t get(int i) const { return (i < LDS_N) ? lds[i * BLOCK] : spill[i - LDS_N]; }
+};
+
+// intersect_mesh (mesh.h:42-118): depth-first walk over child ranges, same visit order as the
+// reference (children of a range are tested first to last, leaves tested on the spot, inner hits
+// pushed; the last pushed range is walked next).  The children of a range are contiguous, so
+// their 16-byte nodes are fetched four at a time before any of them is examined: the loads of a
+// range overlap instead of forming a dependent chain.
+template <int LDS_N, int BLOCK, bool COUNT>
 __device__ inline int intersect_mesh(const GeoView &g, v3 origin, v3 direction, float &min_distance,
-                                     int last_hit_triangle, uint32_t *stack, LaneCounters &cnt)
+                                     int last_hit_triangle, uint32_t *stack_lds, LaneCounters &cnt)
 {
     int triangle_index = -1;
     float distance;
@@ -120,53 +145,61 @@ __device__ inline int intersect_mesh(const GeoView &g, v3 origin, v3 direction, 
     v3 noid = (-origin) / direction;
     v3 inv_dir = 1.0f / direction;
 
-    uint4 root = g.nodes[0];
-    {
-        v3 lo = mk3(wo.x + (float)(root.x & 0xFFFFu) * ws, wo.y + (float)(root.y & 0xFFFFu) * ws, wo.z + (float)(root.z & 0xFFFFu) * ws);
-        v3 hi = mk3(wo.x + (float)(root.x >> 16) * ws, wo.y + (float)(root.y >> 16) * ws, wo.z + (float)(root.z >> 16) * ws);
-        if (!intersect_node(noid, inv_dir, lo, hi, min_distance)) return -1;
-    }
+#define NODE_LO(nd) mk3(wo.x + (float)((nd).x & 0xFFFFu) * ws, wo.y + (float)((nd).y & 0xFFFFu) * ws, wo.z + (float)((nd).z & 0xFFFFu) * ws)
+#define NODE_HI(nd) mk3(wo.x + (float)((nd).x >> 16) * ws, wo.y + (float)((nd).y >> 16) * ws, wo.z + (float)((nd).z >> 16) * ws)
 
-    int sp = 0;
-    stack[0] = root.w;
-    sp = 1;
+    uint4 root = g.nodes[0];
+    if (!node_passes(box_tmin(origin, noid, inv_dir, NODE_LO(root), NODE_HI(root)), min_distance)) return -1;
+
+    TravStack<LDS_N, BLOCK> stack;
+    stack.lds = stack_lds;
+    stack.put(0, root.w);
+    int sp = 1;
 
     while (sp > 0) {
         sp--;
-        uint32_t w = stack[sp * BLOCK];
+        uint32_t w = stack.get(sp);
         uint32_t first_child = w & ~CHROMA_NCHILD_MASK;
         uint32_t nchild = w >> CHROMA_CHILD_BITS;
-        for (uint32_t i = first_child; i < first_child + nchild; i++) {
-            uint4 nd = g.nodes[i];
-            if (COUNT) cnt.nodes++;
-            v3 lo = mk3(wo.x + (float)(nd.x & 0xFFFFu) * ws, wo.y + (float)(nd.y & 0xFFFFu) * ws, wo.z + (float)(nd.z & 0xFFFFu) * ws);
-            v3 hi = mk3(wo.x + (float)(nd.x >> 16) * ws, wo.y + (float)(nd.y >> 16) * ws, wo.z + (float)(nd.z >> 16) * ws);
-            if (intersect_node(noid, inv_dir, lo, hi, min_distance)) {
-                uint32_t nd_nchild = nd.w >> CHROMA_CHILD_BITS;
-                uint32_t nd_child = nd.w & ~CHROMA_NCHILD_MASK;
-                if (nd_nchild == 0) {
-                    if ((int)nd_child != last_hit_triangle) {
-                        if (COUNT) cnt.tris++;
-                        const float4 *t = g.tri + 3 * (size_t)nd_child;
-                        float4 a = t[0], b = t[1], c = t[2];
-                        if (intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance)) {
-                            if (triangle_index == -1 || distance < min_distance) {
-                                triangle_index = (int)nd_child;
-                                min_distance = distance;
+        uint32_t last = first_child + nchild - 1;
+        for (uint32_t base = first_child; base <= last; base += 4) {
+            uint4 nd[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) nd[k] = g.nodes[(base + k <= last) ? base + k : last];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (base + k > last) break;
+                if (COUNT) cnt.nodes++;
+                float tmin = box_tmin(origin, noid, inv_dir, NODE_LO(nd[k]), NODE_HI(nd[k]));
+                if (node_passes(tmin, min_distance)) {
+                    uint32_t nd_nchild = nd[k].w >> CHROMA_CHILD_BITS;
+                    uint32_t nd_child = nd[k].w & ~CHROMA_NCHILD_MASK;
+                    if (nd_nchild == 0) {
+                        if ((int)nd_child != last_hit_triangle) {
+                            if (COUNT) cnt.tris++;
+                            const float4 *t = g.tri + 3 * (size_t)nd_child;
+                            float4 a = t[0], b = t[1], c = t[2];
+                            if (intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance)) {
+                                if (triangle_index == -1 || distance < min_distance) {
+                                    triangle_index = (int)nd_child;
+                                    min_distance = distance;
+                                }
                             }
                         }
+                    } else {
+                        if (sp >= LDS_N + STACK_SCRATCH) {   // cannot happen when the host check passed
+                            cnt.overflows++;
+                            return triangle_index;
+                        }
+                        stack.put(sp, nd[k].w);
+                        sp++;
                     }
-                } else {
-                    if (sp >= STACK_N) {   // cannot happen when the host check passed
-                        cnt.overflows++;
-                        return triangle_index;
-                    }
-                    stack[sp * BLOCK] = nd.w;
-                    sp++;
                 }
             }
         }
     }
+#undef NODE_LO
+#undef NODE_HI
     return triangle_index;
 }
 
@@ -223,18 +256,18 @@ __device__ inline int convert(int c) { return (c & 0x80) ? (int)(0xFFFFFF00u | (
 __device__ inline float get_theta(v3 a, v3 b)                                                         // photon.h:77-81
 { return cm_acosf(cm_fmaxf(-1.0f, cm_fminf(1.0f, dot(a, b)))); }
 
-// fill_state (photon.h:83-135).  The triangle record already holds the three vertices and the
-// material code, so the second triangle fetch of the reference is one 48-B read (L2 hit).
-template <int STACK_N, int BLOCK, bool COUNT>
-__device__ inline void fill_state(State &s, Photon &p, const GeoView &g, uint32_t *stack, LaneCounters &cnt)
+// fill_state (photon.h:83-135), the part after the ray cast.  The triangle record already holds
+// the three vertices and the material code, so the second triangle fetch of the reference is one
+// 48-B read (an L2 hit right after the cast).
+__device__ inline void apply_hit(State &s, Photon &p, const GeoView &g, int triangle, float distance)
 {
-    p.last_hit_triangle = intersect_mesh<STACK_N, BLOCK, COUNT>(g, p.position, p.direction, s.distance_to_boundary,
-                                                                p.last_hit_triangle, stack, cnt);
-    if (p.last_hit_triangle == -1) {
+    p.last_hit_triangle = triangle;
+    s.distance_to_boundary = distance;
+    if (triangle == -1) {
         p.history |= CHROMA_NO_HIT;
         return;
     }
-    const float4 *t = g.tri + 3 * (size_t)p.last_hit_triangle;
+    const float4 *t = g.tri + 3 * (size_t)triangle;
     float4 a = t[0], b = t[1], c = t[2];
     v3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(b.x, b.y, b.z), v2 = mk3(c.x, c.y, c.z);
     uint32_t material_code = __float_as_uint(a.w);
@@ -261,6 +294,14 @@ __device__ inline void fill_state(State &s, Photon &p, const GeoView &g, uint32_
     s.absorption_length = interp_property(g, p.wavelength, row(g.mat_absorption_length, g, material1));
     s.scattering_length = interp_property(g, p.wavelength, row(g.mat_scattering_length, g, material1));
     s.material1 = material1;
+}
+
+template <int LDS_N, int BLOCK, bool COUNT>
+__device__ inline void fill_state(State &s, Photon &p, const GeoView &g, uint32_t *stack, LaneCounters &cnt)
+{
+    float distance;
+    int triangle = intersect_mesh<LDS_N, BLOCK, COUNT>(g, p.position, p.direction, distance, p.last_hit_triangle, stack, cnt);
+    apply_hit(s, p, g, triangle, distance);
 }
 
 // pick_new_direction (photon.h:137-165)
@@ -750,4 +791,20 @@ __device__ inline int propagate_at_surface(Photon &p, State &s, cm_rng &rng, con
         return propagate_at_specular_reflector(p, s);
     else
         return CMD_PASS;
+}
+
+// The part of one loop iteration of propagate.cu:264-301 that follows fill_state.
+// Returns false when the photon's loop ends (BREAK), true when it goes on.
+__device__ inline bool step_after_hit(Photon &p, State &s, cm_rng &rng, const GeoView &g, bool use_weights, int scatter_first)
+{
+    int command = propagate_to_boundary(p, s, rng, g, use_weights, scatter_first);
+    if (command == CMD_BREAK) return false;
+    if (command == CMD_CONTINUE) return true;
+    if (s.surface_index != -1) {
+        command = propagate_at_surface(p, s, rng, g, use_weights);
+        if (command == CMD_BREAK) return false;
+        if (command == CMD_CONTINUE) return true;
+    }
+    propagate_at_boundary(p, s, rng);
+    return true;
 }
