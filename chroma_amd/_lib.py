@@ -13,7 +13,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(_HERE, 'libchroma_hip.so')
+# CHROMA_HIP_LIBRARY points at an alternative build (kernel A/B experiments); default: in-tree
+LIBRARY_PATH = os.environ.get('CHROMA_HIP_LIBRARY') or os.path.join(_HERE, 'libchroma_hip.so')
 
 _f32p = POINTER(c_float)
 _u32p = POINTER(c_uint32)

@@ -69,26 +69,35 @@ struct chroma_geometry {
 // kernels
 // ---------------------------------------------------------------------------------------------------
 #define PROP_BLOCK 64
+#ifndef STACK_LDS
 #define STACK_LDS 24      // traversal stack entries kept in LDS (6 KB per wave); deeper ones spill to scratch
+#endif
+#ifndef RAY_WAVES
+#define RAY_WAVES 1        // __launch_bounds__ waves/SIMD hint for the ray-cast kernel
+#endif
 
-// propagate (chroma/cuda/propagate.cu:217-319)
-template <int STACK_N, bool COUNT>
+// propagate (chroma/cuda/propagate.cu:217-319): up to max_steps steps per photon in one launch.
+// The step loop is wave-uniform (intersect_mesh votes across the wave): lanes whose photon has
+// finished simply sit out the remaining ray casts of their wave.
+template <int LDS_N, bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
 k_propagate(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
             uint32_t *output_queue, uint64_t seed, uint64_t id_base, int max_steps, int use_weights,
             int scatter_first, DeviceCounters *counters)
 {
-    __shared__ uint32_t s_stack[STACK_N * PROP_BLOCK];
-    uint32_t *stack = s_stack + threadIdx.x;
+    __shared__ uint32_t s_lds[TRAV_LDS_WORDS(LDS_N, PROP_BLOCK)];
+    uint32_t *lds = s_lds + threadIdx.x;
 
     int id = blockIdx.x * PROP_BLOCK + threadIdx.x;
-    bool alive = false;
+    bool alive = false, loaded = false;
     uint32_t photon_id = 0;
     LaneCounters cnt = {0, 0, 0, 0};
+    Photon p;
+    cm_rng rng;
+    State s;
 
     if (id < nthreads) {
         photon_id = input_queue ? input_queue[first_photon + id] : (uint32_t)(first_photon + id);
-        Photon p;
         p.position = load3(pv.pos, photon_id);
         p.direction = load3(pv.dir, photon_id);
         p.direction = p.direction / norm(p.direction);
@@ -100,56 +109,63 @@ k_propagate(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint
         p.history = pv.flags[photon_id];
         p.weight = pv.weights[photon_id];
         p.evidx = pv.evidx[photon_id];
-
-        if (!(p.history & CHROMA_TERMINAL_MASK)) {
-            cm_rng rng;
+        if (!(p.history & CHROMA_TERMINAL_MASK)) {          // propagate.cu:258: terminal photons are left untouched
+            loaded = true;
             cm_rng_init(&rng, seed, id_base + photon_id, pv.rng_counters[photon_id]);
-            State s;
-            int steps = 0;
-            while (steps < max_steps) {
-                steps++;
-                if (cm_isnan(p.direction.x * p.direction.y * p.direction.z * p.position.x * p.position.y * p.position.z)) {
-                    p.history |= CHROMA_NO_HIT | CHROMA_NAN_ABORT;
-                    break;
-                }
-                if (COUNT) cnt.steps++;
-                fill_state<STACK_N, PROP_BLOCK, COUNT>(s, p, g, stack, cnt);
-                if (p.last_hit_triangle == -1) break;
-
-                bool go_on = step_after_hit(p, s, rng, g, use_weights != 0, scatter_first);
-                scatter_first = 0;
-                if (!go_on) break;
-            }
-            pv.rng_counters[photon_id] = rng.counter;
-            store3(pv.pos, photon_id, p.position);
-            store3(pv.dir, photon_id, p.direction);
-            store3(pv.pol, photon_id, p.polarization);
-            pv.wavelengths[photon_id] = p.wavelength;
-            pv.t[photon_id] = p.time;
-            pv.flags[photon_id] = p.history;
-            pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
-            pv.weights[photon_id] = p.weight;
-            pv.evidx[photon_id] = p.evidx;
-            alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
         }
+    }
+
+    bool live = loaded;
+    int steps = 0;
+    while (__any(live && steps < max_steps)) {
+        bool stepping = live && steps < max_steps;
+        if (stepping) {
+            steps++;
+            if (cm_isnan(p.direction.x * p.direction.y * p.direction.z * p.position.x * p.position.y * p.position.z)) {
+                p.history |= CHROMA_NO_HIT | CHROMA_NAN_ABORT;
+                live = false;
+                stepping = false;
+            } else if (COUNT) cnt.steps++;
+        }
+        float distance;
+        int triangle = intersect_mesh<LDS_N, PROP_BLOCK, COUNT>(g, p.position, p.direction, distance, p.last_hit_triangle,
+                                                                lds, cnt, stepping);
+        if (stepping) {
+            apply_hit(s, p, g, triangle, distance);
+            if (triangle == -1) {
+                live = false;
+            } else {
+                live = step_after_hit(p, s, rng, g, use_weights != 0, scatter_first);
+                scatter_first = 0;
+            }
+        }
+    }
+
+    if (loaded) {
+        pv.rng_counters[photon_id] = rng.counter;
+        store3(pv.pos, photon_id, p.position);
+        store3(pv.dir, photon_id, p.direction);
+        store3(pv.pol, photon_id, p.polarization);
+        pv.wavelengths[photon_id] = p.wavelength;
+        pv.t[photon_id] = p.time;
+        pv.flags[photon_id] = p.history;
+        pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
+        pv.weights[photon_id] = p.weight;
+        pv.evidx[photon_id] = p.evidx;
+        alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
     }
     if (output_queue) wave_queue_append(output_queue, alive, photon_id);
 
-    if (COUNT || true) {
-        // overflows are always reported; the visit counters only in COUNT builds
-        unsigned long long ov = wave_sum_u64(cnt.overflows);
-        if (COUNT) {
-            unsigned long long st = wave_sum_u64(cnt.steps);
-            unsigned long long nd = wave_sum_u64(cnt.nodes);
-            unsigned long long tr = wave_sum_u64(cnt.tris);
-            if (lane_id() == 0) {
-                atomicAdd(&counters->photon_steps, st);
-                atomicAdd(&counters->nodes_visited, nd);
-                atomicAdd(&counters->triangles_tested, tr);
-            }
+    unsigned long long ov = wave_sum_u64(cnt.overflows);
+    if (COUNT) {
+        unsigned long long st = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        if (lane_id() == 0) {
+            atomicAdd(&counters->photon_steps, st);
+            atomicAdd(&counters->nodes_visited, nd);
+            atomicAdd(&counters->triangles_tested, tr);
         }
-        if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
     }
+    if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
 }
 
 // ---- one step split in two launches (used while many photons are alive) ------------------------
@@ -161,29 +177,36 @@ k_propagate(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint
 #define HIT_NAN  (-2)      // NaN guard fired (propagate.cu:270-273)
 
 template <int LDS_N, bool COUNT>
-__global__ __launch_bounds__(PROP_BLOCK) void
+__global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
 k_raycast(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
           int32_t *hit_triangle, float *hit_distance, DeviceCounters *counters)
 {
-    __shared__ uint32_t s_stack[LDS_N * PROP_BLOCK];
+    __shared__ uint32_t s_lds[TRAV_LDS_WORDS(LDS_N, PROP_BLOCK)];
     int id = blockIdx.x * PROP_BLOCK + threadIdx.x;
     LaneCounters cnt = {0, 0, 0, 0};
+    int tri = HIT_SKIP;
+    float dist = 0.0f;
+    bool cast = false;
+    v3 position = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
+    int last_hit = -1;
     if (id < nthreads) {
         uint32_t photon_id = input_queue ? input_queue[first_photon + id] : (uint32_t)(first_photon + id);
-        int tri = HIT_SKIP;
-        float dist = 0.0f;
         if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
-            v3 position = load3(pv.pos, photon_id);
-            v3 direction = load3(pv.dir, photon_id);
+            position = load3(pv.pos, photon_id);
+            direction = load3(pv.dir, photon_id);
             direction = direction / norm(direction);
             if (cm_isnan(direction.x * direction.y * direction.z * position.x * position.y * position.z)) {
                 tri = HIT_NAN;
             } else {
+                cast = true;
+                last_hit = pv.last_hit_triangles[photon_id];
                 if (COUNT) cnt.steps++;
-                tri = intersect_mesh<LDS_N, PROP_BLOCK, COUNT>(g, position, direction, dist, pv.last_hit_triangles[photon_id],
-                                                               s_stack + threadIdx.x, cnt);
             }
         }
+    }
+    int found = intersect_mesh<LDS_N, PROP_BLOCK, COUNT>(g, position, direction, dist, last_hit, s_lds + threadIdx.x, cnt, cast);
+    if (cast) tri = found;
+    if (id < nthreads) {
         hit_triangle[first_photon + id] = tri;
         hit_distance[first_photon + id] = dist;
     }
@@ -388,20 +411,24 @@ __global__ void k_channel_hits(GeoView g, const uint32_t *flags, const int32_t *
 }
 
 // distance_to_mesh (chroma/cuda/mesh.h:124-151)
-template <int STACK_N, bool COUNT>
+template <int LDS_N, bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
 k_distance_to_mesh(GeoView g, int nthreads, const float *origin, const float *direction, float *distance_out,
                    int32_t *triangle_out, DeviceCounters *counters)
 {
-    __shared__ uint32_t s_stack[STACK_N * PROP_BLOCK];
+    __shared__ uint32_t s_lds[TRAV_LDS_WORDS(LDS_N, PROP_BLOCK)];
     int id = blockIdx.x * PROP_BLOCK + threadIdx.x;
     LaneCounters cnt = {0, 0, 0, 0};
-    if (id < nthreads) {
-        v3 o = load3(origin, id);
-        v3 d = load3(direction, id);
+    bool on = id < nthreads;
+    v3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+    if (on) {
+        o = load3(origin, id);
+        d = load3(direction, id);
         d = d / norm(d);
-        float dist;
-        int tri = intersect_mesh<STACK_N, PROP_BLOCK, COUNT>(g, o, d, dist, -1, s_stack + threadIdx.x, cnt);
+    }
+    float dist;
+    int tri = intersect_mesh<LDS_N, PROP_BLOCK, COUNT>(g, o, d, dist, -1, s_lds + threadIdx.x, cnt, on);
+    if (on) {
         if (tri != -1) distance_out[id] = dist;
         if (triangle_out) triangle_out[id] = tri;
     }

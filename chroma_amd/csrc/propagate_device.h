@@ -2,9 +2,11 @@
 //
 // Behavioural specification: chroma/cuda/{mesh.h,intersect.h,geometry.h,photon.h,random.h,
 // interpolate.h,rotate.h,cx.h} of the reference (cited per function).  The code is written for
-// one photon per lane of a 64-wide wavefront; the traversal stack lives in LDS
-// ([entry][lane] so that the 64 lanes of a wave hit 64 different banks... lanes l and l+32 are
-// served in different LDS cycles, see MI355X_MICROARCH.md "LDS").
+// one photon per lane of a 64-wide wavefront; the traversal stack and the postponed-leaf FIFO
+// live in LDS, laid out [entry][lane] so the 64 lanes of a wave touch 64 different banks
+// (lanes l and l+32 are served in different LDS cycles, MI355X_MICROARCH.md "LDS").
+// NOTE: intersect_mesh contains wave-wide votes; every lane of a wave must call it together
+// (lanes without a ray pass lane_on = false).
 #pragma once
 #include "device_common.h"
 #include <float.h>
@@ -113,11 +115,14 @@ __device__ inline bool node_passes(float tmin, float min_distance)
 }
 
 // ---- mesh.h ---------------------------------------------------------------------------------
-// Traversal stack: a stack entry is the packed `w` word of a node (nchild<<28 | first_child),
-// exactly what the reference keeps in its two 1000-entry local arrays (mesh.h:58-59).  The
-// first LDS_N entries live in LDS ([entry][lane]: one bank per lane), deeper ones -- rare: the
-// observed depth is ~20 -- in a per-lane scratch array, so LDS use stays at LDS_N*256 B per wave.
+// Traversal stack: an entry is the packed `w` word of a node (nchild<<28 | first_child), what the
+// reference keeps in its two 1000-entry local arrays (mesh.h:58-59).  The first LDS_N entries
+// live in LDS ([entry][lane]: one bank per lane), deeper ones -- rare: the observed depth is
+// ~20 -- in a per-lane scratch array, so LDS use stays at LDS_N*256 B per wave.
 #define STACK_SCRATCH 104
+#ifndef TRAV_PENDING
+#define TRAV_PENDING 8      // postponed leaf (triangle) tests per lane, kept in LDS
+#endif
 template <int LDS_N, int BLOCK>
 struct TravStack {
     uint32_t *lds;                       // this lane's column
@@ -125,82 +130,164 @@ struct TravStack {
     __device__ inline void put(int i, uint32_t w) { if (i < LDS_N) lds[i * BLOCK] = w; else spill[i - LDS_N] = w; }
     __device__ inline uint32_t get(int i) const { return (i < LDS_N) ? lds[i * BLOCK] : spill[i - LDS_N]; }
 };
+// LDS words a block of BLOCK lanes needs for intersect_mesh
+#define TRAV_LDS_WORDS(LDS_N, BLOCK) (((LDS_N) + TRAV_PENDING) * (BLOCK))
 
-// intersect_mesh (mesh.h:42-118): depth-first walk over child ranges, same visit order as the
-// reference (children of a range are tested first to last, leaves tested on the spot, inner hits
-// pushed; the last pushed range is walked next).  The children of a range are contiguous, so
-// their 16-byte nodes are fetched four at a time before any of them is examined: the loads of a
-// range overlap instead of forming a dependent chain.
-template <int LDS_N, int BLOCK, bool COUNT>
-__device__ inline int intersect_mesh(const GeoView &g, v3 origin, v3 direction, float &min_distance,
-                                     int last_hit_triangle, uint32_t *stack_lds, LaneCounters &cnt)
+// Fast slab test used when every component of 1/d is finite and moderate (|1/d| < 1e30, i.e.
+// all rays but the exactly/nearly axis-parallel ones).  The box is the node's box grown by one
+// quantum on every side and the dequantisation is folded into two per-ray constants, so a bound
+// costs one convert and one fma:
+//     t = (origin_w + (q -+ 1) * scale - o) / d  =  fma(q, a, b -+ a),  a = scale/d, b = (origin_w - o)/d
+// Growing the box makes this test strictly more permissive than the reference's slab test
+// (intersect.h:107-147, whose rounding differs by far less than a quantum), so it never culls a
+// box the reference would enter: the set of triangles tested still contains the reference's.
+struct RayFast { v3 a, blo, bhi; };
+__device__ inline RayFast ray_fast(const GeoView &g, v3 noid, v3 inv_dir)
+{
+    RayFast r;
+    float ws = g.world_scale;
+    r.a = mk3(ws * inv_dir.x, ws * inv_dir.y, ws * inv_dir.z);
+    v3 b = mk3(cm_fmaf(g.world_origin[0], inv_dir.x, noid.x), cm_fmaf(g.world_origin[1], inv_dir.y, noid.y),
+               cm_fmaf(g.world_origin[2], inv_dir.z, noid.z));
+    r.blo = b - r.a;
+    r.bhi = b + r.a;
+    return r;
+}
+__device__ inline float box_tmin_fast(const RayFast &r, uint4 nd)
+{
+    float t0x = cm_fmaf((float)(nd.x & 0xFFFFu), r.a.x, r.blo.x), t1x = cm_fmaf((float)(nd.x >> 16), r.a.x, r.bhi.x);
+    float t0y = cm_fmaf((float)(nd.y & 0xFFFFu), r.a.y, r.blo.y), t1y = cm_fmaf((float)(nd.y >> 16), r.a.y, r.bhi.y);
+    float t0z = cm_fmaf((float)(nd.z & 0xFFFFu), r.a.z, r.blo.z), t1z = cm_fmaf((float)(nd.z >> 16), r.a.z, r.bhi.z);
+    // v_min_f32 / v_max_f32: a NaN operand yields the other one, like CUDA's min/max
+    float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                 __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+    float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                                 __builtin_fmaxf(t0z, t1z));
+    return (tmin > tmax) ? -1.0f : tmin;
+}
+
+// intersect_mesh (mesh.h:42-118).  Every lane walks its own ray through the tree in the
+// reference's order -- children of a range first to last, inner hits pushed, the last pushed
+// range walked next -- but the loop is organised for a 64-wide wavefront:
+//   * node phase: one node per lane per iteration (fetch, slab test, push or note the leaf); the
+//     body is short and the same for every lane, so lanes stay converged;
+//   * leaf phase: leaves whose box passed are only NOTED (FIFO of TRAV_PENDING per lane in LDS);
+//     when some lane's FIFO is full, or every lane is done, the wave runs the Moeller-Trumbore
+//     tests together, oldest first.
+// Postponing a triangle test only delays the pruning bound (mesh.h:23-29): the walk visits a
+// superset of the reference's nodes and tests a superset of its triangles in the same relative
+// order; an extra triangle lies in a box farther than the current best hit, so it can neither win
+// nor tie.  The returned (triangle, distance) is therefore the reference's, bit for bit.
+// FAST selects the slab test: box_tmin_fast (above) or the reference-exact box_tmin.
+template <int LDS_N, int BLOCK, bool COUNT, bool FAST>
+__device__ inline int intersect_mesh_walk(const GeoView &g, v3 origin, v3 direction, v3 noid, v3 inv_dir,
+                                          float &min_distance, int last_hit_triangle, uint32_t *lds,
+                                          LaneCounters &cnt, bool lane_on)
 {
     int triangle_index = -1;
-    float distance;
     min_distance = -1.0f;
 
     const v3 wo = mk3(g.world_origin[0], g.world_origin[1], g.world_origin[2]);
     const float ws = g.world_scale;
-
-    v3 noid = (-origin) / direction;
-    v3 inv_dir = 1.0f / direction;
+    RayFast rf;
+    if (FAST) rf = ray_fast(g, noid, inv_dir);
 
 #define NODE_LO(nd) mk3(wo.x + (float)((nd).x & 0xFFFFu) * ws, wo.y + (float)((nd).y & 0xFFFFu) * ws, wo.z + (float)((nd).z & 0xFFFFu) * ws)
 #define NODE_HI(nd) mk3(wo.x + (float)((nd).x >> 16) * ws, wo.y + (float)((nd).y >> 16) * ws, wo.z + (float)((nd).z >> 16) * ws)
-
-    uint4 root = g.nodes[0];
-    if (!node_passes(box_tmin(origin, noid, inv_dir, NODE_LO(root), NODE_HI(root)), min_distance)) return -1;
+#define NODE_TMIN(nd) (FAST ? box_tmin_fast(rf, nd) : box_tmin(origin, noid, inv_dir, NODE_LO(nd), NODE_HI(nd)))
 
     TravStack<LDS_N, BLOCK> stack;
-    stack.lds = stack_lds;
-    stack.put(0, root.w);
-    int sp = 1;
+    stack.lds = lds;
+    uint32_t *pending = lds + LDS_N * BLOCK;
+    int sp = 0, npend = 0;
+    uint32_t cur = 1, end = 0;            // empty range
+    bool active = false;
+    if (lane_on) {
+        uint4 root = g.nodes[0];
+        if (node_passes(NODE_TMIN(root), min_distance)) {
+            active = true;
+            cur = root.w & ~CHROMA_NCHILD_MASK;
+            end = cur + (root.w >> CHROMA_CHILD_BITS) - 1;
+        }
+    }
 
-    while (sp > 0) {
-        sp--;
-        uint32_t w = stack.get(sp);
-        uint32_t first_child = w & ~CHROMA_NCHILD_MASK;
-        uint32_t nchild = w >> CHROMA_CHILD_BITS;
-        uint32_t last = first_child + nchild - 1;
-        for (uint32_t base = first_child; base <= last; base += 4) {
-            uint4 nd[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) nd[k] = g.nodes[(base + k <= last) ? base + k : last];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (base + k > last) break;
-                if (COUNT) cnt.nodes++;
-                float tmin = box_tmin(origin, noid, inv_dir, NODE_LO(nd[k]), NODE_HI(nd[k]));
-                if (node_passes(tmin, min_distance)) {
-                    uint32_t nd_nchild = nd[k].w >> CHROMA_CHILD_BITS;
-                    uint32_t nd_child = nd[k].w & ~CHROMA_NCHILD_MASK;
-                    if (nd_nchild == 0) {
-                        if ((int)nd_child != last_hit_triangle) {
-                            if (COUNT) cnt.tris++;
-                            const float4 *t = g.tri + 3 * (size_t)nd_child;
-                            float4 a = t[0], b = t[1], c = t[2];
-                            if (intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance)) {
-                                if (triangle_index == -1 || distance < min_distance) {
-                                    triangle_index = (int)nd_child;
-                                    min_distance = distance;
-                                }
-                            }
-                        }
+    // all 64 lanes stay in this loop until the whole wave is done (wave-uniform branches only)
+    while (__any(active)) {
+        // ---- node phase
+        do {
+            if (active) {
+                if (cur > end) {
+                    if (sp == 0) {
+                        active = false;
                     } else {
-                        if (sp >= LDS_N + STACK_SCRATCH) {   // cannot happen when the host check passed
+                        sp--;
+                        uint32_t w = stack.get(sp);
+                        cur = w & ~CHROMA_NCHILD_MASK;
+                        end = cur + (w >> CHROMA_CHILD_BITS) - 1;
+                    }
+                }
+                if (active) {
+                    uint4 nd = g.nodes[cur];
+                    cur++;
+                    if (COUNT) cnt.nodes++;
+                    float tmin = NODE_TMIN(nd);
+                    if (node_passes(tmin, min_distance)) {
+                        uint32_t nd_child = nd.w & ~CHROMA_NCHILD_MASK;
+                        if ((nd.w >> CHROMA_CHILD_BITS) == 0) {
+                            if ((int)nd_child != last_hit_triangle) {
+                                pending[npend * BLOCK] = nd_child;
+                                npend++;
+                            }
+                        } else if (sp >= LDS_N + STACK_SCRATCH) {   // cannot happen when the host check passed
                             cnt.overflows++;
-                            return triangle_index;
+                            active = false;
+                        } else {
+                            stack.put(sp, nd.w);
+                            sp++;
                         }
-                        stack.put(sp, nd[k].w);
-                        sp++;
+                    }
+                }
+            }
+        } while (!__any(npend >= TRAV_PENDING) && __any(active));
+
+        // ---- leaf phase: postponed triangle tests, oldest first (the reference's order)
+        for (int j = 0; __any(j < npend); j++) {
+            if (j < npend) {
+                uint32_t tri = pending[j * BLOCK];
+                if (COUNT) cnt.tris++;
+                const float4 *t = g.tri + 3 * (size_t)tri;
+                float4 a = t[0], b = t[1], c = t[2];
+                float distance;
+                if (intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance)) {
+                    if (triangle_index == -1 || distance < min_distance) {
+                        triangle_index = (int)tri;
+                        min_distance = distance;
                     }
                 }
             }
         }
+        npend = 0;
     }
 #undef NODE_LO
 #undef NODE_HI
+#undef NODE_TMIN
     return triangle_index;
+}
+
+template <int LDS_N, int BLOCK, bool COUNT>
+__device__ inline int intersect_mesh(const GeoView &g, v3 origin, v3 direction, float &min_distance,
+                                     int last_hit_triangle, uint32_t *lds, LaneCounters &cnt, bool lane_on = true)
+{
+    const v3 noid = (-origin) / direction;
+    const v3 inv_dir = 1.0f / direction;
+    // |1/d| < 1e30 on all axes (false for inf and NaN): the whole wave takes the fast slab test
+    bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                    cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+    if (__any(lane_on && !moderate))
+        return intersect_mesh_walk<LDS_N, BLOCK, COUNT, false>(g, origin, direction, noid, inv_dir, min_distance,
+                                                               last_hit_triangle, lds, cnt, lane_on);
+    return intersect_mesh_walk<LDS_N, BLOCK, COUNT, true>(g, origin, direction, noid, inv_dir, min_distance,
+                                                          last_hit_triangle, lds, cnt, lane_on);
 }
 
 // ---- random.h / interpolate.h -----------------------------------------------------------------
@@ -296,13 +383,6 @@ __device__ inline void apply_hit(State &s, Photon &p, const GeoView &g, int tria
     s.material1 = material1;
 }
 
-template <int LDS_N, int BLOCK, bool COUNT>
-__device__ inline void fill_state(State &s, Photon &p, const GeoView &g, uint32_t *stack, LaneCounters &cnt)
-{
-    float distance;
-    int triangle = intersect_mesh<LDS_N, BLOCK, COUNT>(g, p.position, p.direction, distance, p.last_hit_triangle, stack, cnt);
-    apply_hit(s, p, g, triangle, distance);
-}
 
 // pick_new_direction (photon.h:137-165)
 __device__ inline v3 pick_new_direction(v3 axis, float theta, float phi)
