@@ -115,7 +115,9 @@ SIGNATURES = {
     'chroma_bvh_build': (c_int32, [c_void_p, c_uint32, c_void_p, c_uint32, POINTER(c_float), c_float, c_int32,
                                    POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint32)]),
     'chroma_bvh_fetch': (c_int32, [c_void_p, c_void_p, c_void_p]),
+    'chroma_bvh_data': (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p)]),
     'chroma_bvh_free': (c_int32, [c_void_p]),
+    'chroma_dedupe_vertices': (c_int32, [c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, POINTER(c_uint64)]),
     'chroma_propagate_stats_read': (c_int32, [c_void_p, POINTER(PropagateStats)]),
     'chroma_set_counting': (c_int32, [c_void_p, c_int32]),
 }
@@ -174,10 +176,25 @@ def bvh_build(vertices, triangles, world_origin, world_scale, target_degree=3):
     check(lib.chroma_bvh_build(ptr(vertices), len(vertices), ptr(triangles), len(triangles), origin,
                                c_float(float(world_scale)), int(target_degree),
                                ctypes.byref(handle), ctypes.byref(nnodes), ctypes.byref(nlayers)))
-    try:
-        nodes = np.empty(nnodes.value, dtype=uint4)
-        bounds = np.empty(nlayers.value + 1, dtype=np.uint64)
-        check(lib.chroma_bvh_fetch(handle, ptr(nodes), ptr(bounds)))
-    finally:
-        lib.chroma_bvh_free(handle)
+    # view the builder's own buffer (no copy); it is released when the array is garbage-collected
+    p_nodes, p_bounds = c_void_p(), c_void_p()
+    check(lib.chroma_bvh_data(handle, ctypes.byref(p_nodes), ctypes.byref(p_bounds)))
+    raw = (ctypes.c_uint32 * (4 * nnodes.value)).from_address(p_nodes.value)
+    nodes = np.frombuffer(raw, dtype=uint4)
+    bounds = np.array((ctypes.c_uint64 * (nlayers.value + 1)).from_address(p_bounds.value), dtype=np.uint64)
+    import weakref
+    weakref.finalize(raw, lib.chroma_bvh_free, handle)
     return nodes, bounds.astype(np.int64)
+
+
+def dedupe_vertices(vertices, triangles):
+    """Native Mesh.remove_duplicate_vertices.  ``triangles`` (a C-contiguous 32-bit integer array)
+    is remapped IN PLACE; returns the unique vertices (a view of a buffer of the original size)."""
+    lib = load()
+    vertices = np.ascontiguousarray(vertices, dtype=np.float32)
+    if not (triangles.flags['C_CONTIGUOUS'] and triangles.dtype.itemsize == 4 and triangles.dtype.kind in 'iu'):
+        raise ValueError('triangles must be a C-contiguous int32/uint32 array')
+    unique = np.empty_like(vertices)
+    nunique = c_uint64()
+    check(lib.chroma_dedupe_vertices(ptr(vertices), len(vertices), ptr(triangles), triangles.size, ptr(unique), ctypes.byref(nunique)))
+    return unique[:nunique.value]

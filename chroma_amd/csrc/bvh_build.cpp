@@ -12,10 +12,23 @@
 #include <algorithm>
 #include <thread>
 #include <vector>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/chroma_hip.h"
+#include "host_utils.h"
 
 namespace {
+struct Timer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool on = getenv("CHROMA_BVH_VERBOSE") != nullptr;
+    void lap(const char *what) {
+        auto t1 = std::chrono::steady_clock::now();
+        if (on) fprintf(stderr, "[bvh] %-28s %.2f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 struct Node { uint32_t x, y, z, w; };
 const int MAX_CHILD = 15;   // 2^(32-28) - 1, chroma/bvh/grid.py:6
@@ -37,45 +50,26 @@ inline uint64_t spread3_16(uint32_t input)   // cuda/bvh.cu:42-52
 
 inline uint32_t quantize(float v, float origin, float scale)   // cuda/bvh.cu:65-69: truncate
 {
-    volatile float d = v - origin;     // keep the two roundings separate (no contraction)
-    volatile float q = d / scale;
+    float d = v - origin;              // -ffp-contract=off: subtraction and division round separately
+    float q = d / scale;
     return (uint32_t)q;
 }
 
-template <class F>
-void parallel_for(size_t n, F f)
-{
-    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
-    if (n < (1u << 16)) nt = 1;
-    if (nt == 1) { f(0, n); return; }
-    std::vector<std::thread> th;
-    size_t chunk = (n + nt - 1) / nt;
-    for (unsigned t = 0; t < nt; t++) {
-        size_t lo = std::min(n, (size_t)t * chunk), hi = std::min(n, lo + chunk);
-        if (lo < hi) th.emplace_back([=] { f(lo, hi); });
-    }
-    for (auto &t : th) t.join();
-}
+using chroma_host::parallel_for;
 
-// stable LSD radix sort of 48-bit keys with a 32-bit payload (16 bits per pass)
-void radix_sort_48(std::vector<uint64_t> &keys, std::vector<uint32_t> &vals)
+// stable sort of (Morton code, triangle id) records: three 16-bit LSD passes on all cores
+struct MortonRec { uint64_t code; uint32_t id; uint32_t pad; };
+void sort_by_morton(std::vector<MortonRec> &recs)
 {
-    size_t n = keys.size();
-    std::vector<uint64_t> k2(n);
-    std::vector<uint32_t> v2(n);
+    size_t n = recs.size();
+    std::vector<MortonRec> tmp(n);
+    MortonRec *in = recs.data(), *out = tmp.data();
     for (int pass = 0; pass < 3; pass++) {
         int shift = 16 * pass;
-        std::vector<size_t> count(65536 + 1, 0);
-        for (size_t i = 0; i < n; i++) count[((keys[i] >> shift) & 0xFFFF) + 1]++;
-        for (size_t b = 0; b < 65536; b++) count[b + 1] += count[b];
-        for (size_t i = 0; i < n; i++) {
-            size_t dst = count[(keys[i] >> shift) & 0xFFFF]++;
-            k2[dst] = keys[i];
-            v2[dst] = vals[i];
-        }
-        keys.swap(k2);
-        vals.swap(v2);
+        bool skipped = chroma_host::radix_pass16(n, in, out, [shift](const MortonRec &r) { return (uint32_t)((r.code >> shift) & 0xFFFFu); });
+        if (!skipped) std::swap(in, out);
     }
+    if (in != recs.data()) memcpy(recs.data(), in, n * sizeof(MortonRec));
 }
 
 size_t count_unique_sorted_shifted(const std::vector<uint64_t> &m, int shift)
@@ -112,50 +106,62 @@ int chroma_bvh_build(const float *vertices, uint32_t nvertices, const uint32_t *
 {
     if (!vertices || !triangles || !handle || ntriangles == 0 || ntriangles >= (1u << CHROMA_CHILD_BITS) || target_degree < 1)
         return CHROMA_ERR_INVALID;
-    for (size_t i = 0; i < (size_t)ntriangles * 3; i += 1)
-        if (triangles[i] >= nvertices) return CHROMA_ERR_INVALID;
+    {
+        std::vector<int> bad(1, 0);
+        chroma_host::parallel_for((size_t)ntriangles * 3, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) if (triangles[i] >= nvertices) { bad[0] = 1; return; }
+        });
+        if (bad[0]) return CHROMA_ERR_INVALID;
+    }
 
+    Timer timer;
+    timer.lap("validate");
     const float ox = world_origin[0], oy = world_origin[1], oz = world_origin[2];
     size_t n = ntriangles;
-    std::vector<Node> leaves(n);
     std::vector<uint64_t> morton(n);
-    std::vector<uint32_t> order(n);
+    std::vector<MortonRec> recs(n);
 
-    // make_leaves (cuda/bvh.cu:149-203)
+    timer.lap("allocate");
+    // make_leaves (cuda/bvh.cu:149-203), split in two: Morton codes now, the boxes once the
+    // leaves' final order is known (saves one 16-byte-per-triangle array)
+    const float org[3] = {ox, oy, oz};
+    auto leaf_of = [&](size_t i, uint64_t *code) -> Node {
+        const float *a = vertices + 3 * (size_t)triangles[3 * i];
+        const float *b = vertices + 3 * (size_t)triangles[3 * i + 1];
+        const float *c = vertices + 3 * (size_t)triangles[3 * i + 2];
+        uint32_t ql[3], qu[3], qc[3];
+        for (int k = 0; k < 3; k++) {
+            float lower = fminf(fminf(a[k], b[k]), c[k]);
+            float upper = fmaxf(fmaxf(a[k], b[k]), c[k]);
+            float s1 = a[k] + b[k];        // compiled with -ffp-contract=off: three separate roundings
+            float s2 = s1 + c[k];
+            float cen = s2 / 3.0f;
+            ql[k] = quantize(lower, org[k], world_scale);
+            if (ql[k] > 0) ql[k]--;
+            qu[k] = quantize(upper, org[k], world_scale) + 1;
+            qc[k] = quantize(cen, org[k], world_scale);
+        }
+        if (code) *code = spread3_16(qc[0]) | (spread3_16(qc[1]) << 1) | (spread3_16(qc[2]) << 2);
+        return Node{ql[0] | (qu[0] << 16), ql[1] | (qu[1] << 16), ql[2] | (qu[2] << 16), (uint32_t)i};
+    };
     parallel_for(n, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; i++) {
-            const float *a = vertices + 3 * (size_t)triangles[3 * i];
-            const float *b = vertices + 3 * (size_t)triangles[3 * i + 1];
-            const float *c = vertices + 3 * (size_t)triangles[3 * i + 2];
-            float lower[3], upper[3], cen[3];
-            for (int k = 0; k < 3; k++) {
-                lower[k] = fminf(fminf(a[k], b[k]), c[k]);
-                upper[k] = fmaxf(fmaxf(a[k], b[k]), c[k]);
-                volatile float s1 = a[k] + b[k];
-                volatile float s2 = s1 + c[k];
-                volatile float s3 = s2 / 3.0f;
-                cen[k] = s3;
-            }
-            const float org[3] = {ox, oy, oz};
-            uint32_t ql[3], qu[3], qc[3];
-            for (int k = 0; k < 3; k++) {
-                ql[k] = quantize(lower[k], org[k], world_scale);
-                if (ql[k] > 0) ql[k]--;
-                qu[k] = quantize(upper[k], org[k], world_scale) + 1;
-                qc[k] = quantize(cen[k], org[k], world_scale);
-            }
-            morton[i] = spread3_16(qc[0]) | (spread3_16(qc[1]) << 1) | (spread3_16(qc[2]) << 2);
-            leaves[i] = Node{ql[0] | (qu[0] << 16), ql[1] | (qu[1] << 16), ql[2] | (qu[2] << 16), (uint32_t)i};
-            order[i] = (uint32_t)i;
+            leaf_of(i, &recs[i].code);
+            recs[i].id = (uint32_t)i;
+            recs[i].pad = 0;
         }
     });
 
+    timer.lap("make_leaves");
     // Morton order (grid.py:26-28; stable, so equal codes keep triangle order)
-    radix_sort_48(morton, order);
+    sort_by_morton(recs);
+    timer.lap("morton sort");
     std::vector<Node> sorted(n);
-    parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) sorted[i] = leaves[order[i]]; });
-    leaves.clear(); leaves.shrink_to_fit();
-    order.clear(); order.shrink_to_fit();
+    parallel_for(n, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) { sorted[i] = leaf_of(recs[i].id, nullptr); morton[i] = recs[i].code; }
+    });
+    std::vector<MortonRec>().swap(recs);
+    timer.lap("morton sort + gather");
 
     std::vector<std::vector<Node>> layers;   // leaves first here, reversed at the end
     layers.push_back(std::move(sorted));
@@ -209,6 +215,7 @@ int chroma_bvh_build(const float *vertices, uint32_t nvertices, const uint32_t *
         layers.push_back(std::move(parents));
     }
 
+    timer.lap("parent layers");
     // concatenate_layers (gpu/bvh.py:239-267): root first; child index += start of next layer
     BvhResult *res = new BvhResult;
     size_t nl = layers.size();
@@ -238,6 +245,7 @@ int chroma_bvh_build(const float *vertices, uint32_t nvertices, const uint32_t *
             }
         });
     }
+    timer.lap("concatenate + collapse");
     *handle = res;
     if (nnodes) *nnodes = total;
     if (nlayers) *nlayers = (uint32_t)nl;
@@ -250,6 +258,15 @@ int chroma_bvh_fetch(void *handle, uint32_t *nodes_out, uint64_t *layer_bounds_o
     BvhResult *res = (BvhResult *)handle;
     if (nodes_out) memcpy(nodes_out, res->nodes.data(), res->nodes.size() * sizeof(Node));
     if (layer_bounds_out) memcpy(layer_bounds_out, res->layer_bounds.data(), res->layer_bounds.size() * sizeof(uint64_t));
+    return CHROMA_OK;
+}
+
+int chroma_bvh_data(void *handle, const uint32_t **nodes, const uint64_t **layer_bounds)
+{
+    if (!handle) return CHROMA_ERR_INVALID;
+    BvhResult *res = (BvhResult *)handle;
+    if (nodes) *nodes = (const uint32_t *)res->nodes.data();
+    if (layer_bounds) *layer_bounds = res->layer_bounds.data();
     return CHROMA_OK;
 }
 

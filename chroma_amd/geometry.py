@@ -19,6 +19,9 @@ from chroma_amd.log import logger
 # (chroma/geometry.py:17): 60..995 nm in 5 nm steps, 188 samples.
 standard_wavelengths = np.arange(60, 1000, 5).astype(np.float32)
 
+# meshes with at least this many vertices are de-duplicated by the native (multi-threaded) code
+NATIVE_DEDUPE_THRESHOLD = 200000
+
 
 class Mesh(object):
     """Triangle mesh: float32 vertices (n,3) and int32 vertex indices (m,3)."""
@@ -57,6 +60,13 @@ class Mesh(object):
     def remove_duplicate_vertices(self):
         """Merge identical vertices; the survivors end up in lexicographic (x, y, z) order,
         which is what the reference's structured-array ``np.unique`` produces."""
+        if len(self.vertices) >= NATIVE_DEDUPE_THRESHOLD:
+            # same result from the multi-threaded native sort (chroma_dedupe_vertices)
+            from chroma_amd import _lib
+            if not self.triangles.flags['OWNDATA'] or not self.triangles.flags['C_CONTIGUOUS']:
+                self.triangles = np.array(self.triangles, order='C')      # remapped in place below
+            self.vertices = _lib.dedupe_vertices(self.vertices, self.triangles)
+            return
         unique, inverse = np.unique(self.vertices, axis=0, return_inverse=True)
         self.vertices = np.ascontiguousarray(unique, dtype=np.float32)
         self.triangles = np.asarray(inverse).reshape(-1)[self.triangles].astype(self.triangles.dtype)
@@ -293,14 +303,29 @@ class Geometry(object):
         nv = np.cumsum([0] + [len(s.mesh.vertices) for s in self.solids])
         nt = np.cumsum([0] + [len(s.mesh.triangles) for s in self.solids])
         vertices = np.empty((nv[-1], 3), dtype=np.float32)
-        triangles = np.empty((nt[-1], 3), dtype=np.uint32)
+        triangles = np.empty((nt[-1], 3), dtype=np.int32)
         logger.info('Flattening detector mesh...')
         logger.info('  triangles: %d' % len(triangles))
         logger.info('  vertices:  %d' % len(vertices))
-        for i, solid in enumerate(self.solids):
-            vertices[nv[i]:nv[i + 1]] = np.inner(solid.mesh.vertices, self.solid_rotations[i]) \
-                + self.solid_displacements[i]
-            triangles[nt[i]:nt[i + 1]] = solid.mesh.triangles + nv[i]
+        # runs of consecutive placements of the same Solid (thousands of identical PMTs) are
+        # transformed in one batched product: v' = v . R^T + d, as np.inner(v, R) + d per solid
+        i, nsolids = 0, len(self.solids)
+        while i < nsolids:
+            solid = self.solids[i]
+            j = i + 1
+            while j < nsolids and self.solids[j] is solid and j - i < 512:
+                j += 1
+            mv, mt = solid.mesh.vertices, solid.mesh.triangles
+            if j - i == 1:
+                vertices[nv[i]:nv[i + 1]] = np.inner(mv, self.solid_rotations[i]) + self.solid_displacements[i]
+                triangles[nt[i]:nt[i + 1]] = mt + nv[i]
+            else:
+                rot = np.stack(self.solid_rotations[i:j])                                  # (k,3,3)
+                disp = np.stack([np.asarray(d, dtype=np.float32) for d in self.solid_displacements[i:j]])
+                block = np.matmul(mv[None, :, :], np.transpose(rot, (0, 2, 1))) + disp[:, None, :]
+                vertices[nv[i]:nv[j]] = block.reshape(-1, 3)
+                triangles[nt[i]:nt[j]] = (mt[None, :, :] + nv[i:j, None, None]).reshape(-1, 3)
+            i = j
         self.mesh = Mesh(vertices, triangles, remove_duplicate_vertices=True, remove_null_triangles=False)
         self.colors = np.concatenate([s.color for s in self.solids])
         self.solid_id = np.concatenate([np.full(len(s.mesh.triangles), i, dtype=np.uint32)

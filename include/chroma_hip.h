@@ -265,7 +265,16 @@ int chroma_bvh_build(const float *vertices, uint32_t nvertices, const uint32_t *
                      const float world_origin[3], float world_scale, int32_t target_degree,
                      void **handle, uint64_t *nnodes, uint32_t *nlayers);
 int chroma_bvh_fetch(void *handle, uint32_t *nodes_out, uint64_t *layer_bounds_out);
+/* zero-copy access to the arrays owned by the handle (valid until chroma_bvh_free) */
+int chroma_bvh_data(void *handle, const uint32_t **nodes, const uint64_t **layer_bounds);
 int chroma_bvh_free(void *handle);
+
+/* Merge identical vertices of a flattened mesh: replaces Mesh.remove_duplicate_vertices
+ * (chroma/geometry.py:58-67, np.unique on a structured view) for large meshes.  The survivors
+ * are written to `unique_out` ([nvertices][3] capacity) in lexicographic (x, y, z) order and
+ * `triangle_indices` ([nindices], may be NULL) is remapped in place.  Host-side, all cores. */
+int chroma_dedupe_vertices(const float *vertices, uint64_t nvertices, uint32_t *triangle_indices,
+                           uint64_t nindices, float *unique_out, uint64_t *nunique);
 
 /* accumulated counters of chroma_propagate_step launches since the last read */
 int chroma_propagate_stats_read(chroma_ctx *ctx, chroma_propagate_stats *stats);

@@ -13,10 +13,9 @@ for grp in \
   "FETCH_SIZE" \
   "WRITE_SIZE" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" \
-  "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
-  "GRBM_GUI_ACTIVE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum" ; do
+  "GRBM_GUI_ACTIVE" ; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $out/pass$i -- "$@" > $out/pass$i.stdout 2> $out/pass$i.stderr
+  timeout -k 5 120 rocprofv3 --pmc $grp --output-format csv -d $out/pass$i -- "$@" > $out/pass$i.stdout 2> $out/pass$i.stderr
   echo "pass $i rc=$? : $grp"
 done
 python tools/pmc_summary.py $out
