@@ -52,6 +52,7 @@ struct chroma_ctx {
     uint32_t *d_words = nullptr;        // 16 words
     uint32_t *h_words = nullptr;        // pinned mirror
     int counting = 0;
+    int persistent_waves = 256 * 20 * 4;   // grid of the persistent ray-cast kernel (set from the device at init)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 
@@ -209,6 +210,232 @@ k_raycast(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32
     if (id < nthreads) {
         hit_triangle[first_photon + id] = tri;
         hit_distance[first_photon + id] = dist;
+    }
+    unsigned long long ov = wave_sum_u64(cnt.overflows);
+    if (COUNT) {
+        unsigned long long st = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        if (lane_id() == 0) {
+            atomicAdd(&counters->photon_steps, st);
+            atomicAdd(&counters->nodes_visited, nd);
+            atomicAdd(&counters->triangles_tested, tr);
+        }
+    }
+    if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
+}
+
+// ---- persistent ray cast with lane refill ---------------------------------------------------------
+// One ray per lane, but a lane that finishes its ray takes the next one from the queue (one atomic
+// per wave per refill), so the 64 lanes of a wave stay busy although their rays need very
+// different numbers of node visits (measured: 26 % of the lanes active without refill).
+// Traversal is the walk of intersect_mesh (same visit order, postponed triangle tests); the stack
+// lives in LDS only.  The rare rays this kernel cannot take -- a component of 1/d that is not
+// "moderate" (exactly or nearly axis-parallel) or a stack deeper than RAY_LDS_STACK -- are marked
+// HIT_RETRY and done by k_raycast_retry with the general code.
+#define HIT_RETRY (-4)
+#ifndef RAY_LDS_STACK
+#define RAY_LDS_STACK 24
+#endif
+#ifndef RAY_REFILL_MIN
+#define RAY_REFILL_MIN 12     // refill once this many lanes are idle
+#endif
+
+template <bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
+k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
+                     int32_t *hit_triangle, float *hit_distance, uint32_t *work_counter, uint32_t *retry_counter,
+                     DeviceCounters *counters)
+{
+    __shared__ uint32_t s_lds[(RAY_LDS_STACK + TRAV_PENDING) * PROP_BLOCK];
+    uint32_t *stack = s_lds + threadIdx.x;
+    uint32_t *pending = stack + RAY_LDS_STACK * PROP_BLOCK;
+    const unsigned lane = lane_id();
+    LaneCounters cnt = {0, 0, 0, 0};
+
+    // per-lane ray state
+    bool has_ray = false, active = false;
+    int slot = 0;
+    v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
+    RayFast rf;
+    rf.a = rf.blo = rf.bhi = mk3(0.f, 0.f, 0.f);
+    int last_hit = -1, triangle_index = -1;
+    float min_distance = -1.0f;
+    uint32_t cur = 1, end = 0;
+    int sp = 0, npend = 0;
+    bool exhausted = false;     // wave-uniform: the queue has no more rays
+
+    for (;;) {
+        // ---- refill idle lanes
+        unsigned long long idle_mask = __ballot(!has_ray);
+        int n_idle = __popcll(idle_mask);
+        if (!exhausted && (n_idle >= RAY_REFILL_MIN || n_idle == WAVE)) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(work_counter, (uint32_t)n_idle);
+            base = __shfl(base, 0);
+            if (base + (uint32_t)n_idle >= (uint32_t)nthreads) exhausted = true;
+            if (!has_ray) {
+                uint32_t idx = base + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (idx < (uint32_t)nthreads) {
+                    slot = first_photon + (int)idx;
+                    uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
+                    int result = HIT_SKIP;
+                    if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
+                        origin = load3(pv.pos, photon_id);
+                        direction = load3(pv.dir, photon_id);
+                        direction = direction / norm(direction);
+                        if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
+                            result = HIT_NAN;
+                        } else {
+                            v3 noid = (-origin) / direction;
+                            v3 inv_dir = 1.0f / direction;
+                            bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                                            cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+                            if (!moderate) {
+                                result = HIT_RETRY;
+                            } else {
+                                if (COUNT) cnt.steps++;
+                                rf = ray_fast(g, noid, inv_dir);
+                                last_hit = pv.last_hit_triangles[photon_id];
+                                triangle_index = -1;
+                                min_distance = -1.0f;
+                                sp = 0;
+                                npend = 0;
+                                uint4 root = g.nodes[0];
+                                has_ray = true;
+                                if (node_passes(box_tmin_fast(rf, root), min_distance)) {
+                                    active = true;
+                                    cur = root.w & ~CHROMA_NCHILD_MASK;
+                                    end = cur + (root.w >> CHROMA_CHILD_BITS) - 1;
+                                } else {
+                                    active = false;      // misses the world box: result -1 written below
+                                }
+                                result = 0;
+                            }
+                        }
+                    }
+                    if (!has_ray) {                      // nothing to cast for this slot
+                        hit_triangle[slot] = result;
+                        hit_distance[slot] = 0.0f;
+                        if (result == HIT_RETRY) atomicAdd(retry_counter, 1u);
+                    }
+                }
+            }
+        }
+        if (!__any(has_ray)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- node phase: one node per active lane per iteration; it ends when a lane's FIFO of
+        // postponed leaves is full, or enough lanes have finished to make a refill worthwhile
+        const int stop_at = exhausted ? 0 : max(0, __popcll(__ballot(active)) - RAY_REFILL_MIN);
+        do {
+            if (active) {
+                if (cur > end) {
+                    if (sp == 0) {
+                        active = false;
+                    } else {
+                        sp--;
+                        uint32_t w = stack[sp * PROP_BLOCK];
+                        cur = w & ~CHROMA_NCHILD_MASK;
+                        end = cur + (w >> CHROMA_CHILD_BITS) - 1;
+                    }
+                }
+                if (active) {
+                    uint4 nd = g.nodes[cur];
+                    cur++;
+                    if (COUNT) cnt.nodes++;
+                    float tmin = box_tmin_fast(rf, nd);
+                    if (node_passes(tmin, min_distance)) {
+                        uint32_t nd_child = nd.w & ~CHROMA_NCHILD_MASK;
+                        if ((nd.w >> CHROMA_CHILD_BITS) == 0) {
+                            if ((int)nd_child != last_hit) {
+                                pending[npend * PROP_BLOCK] = nd_child;
+                                npend++;
+                            }
+                        } else if (sp >= RAY_LDS_STACK) {
+                            // deeper than the LDS stack: hand the whole ray to the retry kernel
+                            active = false;
+                            npend = 0;
+                            triangle_index = HIT_RETRY;
+                        } else {
+                            stack[sp * PROP_BLOCK] = nd.w;
+                            sp++;
+                        }
+                    }
+                }
+            }
+        } while (!__any(npend >= TRAV_PENDING) && __popcll(__ballot(active)) > stop_at);
+
+        // ---- leaf phase: postponed triangle tests, oldest first
+        for (int j = 0; __any(j < npend); j++) {
+            if (j < npend) {
+                uint32_t tri = pending[j * PROP_BLOCK];
+                if (COUNT) cnt.tris++;
+                const float4 *t = g.tri + 3 * (size_t)tri;
+                float4 a = t[0], b = t[1], c = t[2];
+                float distance;
+                if (intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance)) {
+                    if (triangle_index == -1 || distance < min_distance) {
+                        triangle_index = (int)tri;
+                        min_distance = distance;
+                    }
+                }
+            }
+        }
+        npend = 0;
+
+        // ---- retire finished rays
+        if (has_ray && !active) {
+            hit_triangle[slot] = triangle_index;
+            hit_distance[slot] = min_distance;
+            if (triangle_index == HIT_RETRY) atomicAdd(retry_counter, 1u);
+            has_ray = false;
+        }
+    }
+
+    if (COUNT) {
+        unsigned long long st = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        if (lane == 0) {
+            atomicAdd(&counters->photon_steps, st);
+            atomicAdd(&counters->nodes_visited, nd);
+            atomicAdd(&counters->triangles_tested, tr);
+        }
+    }
+}
+
+// Second pass for the slots k_raycast_persistent marked HIT_RETRY (normally none): the general
+// walk (reference-exact slab test, stack spilling to scratch).  A small fixed grid strides over
+// the queue; it returns at once when the retry counter is zero.
+template <bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK) void
+k_raycast_retry(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
+                int32_t *hit_triangle, float *hit_distance, const uint32_t *retry_counter, DeviceCounters *counters)
+{
+    __shared__ uint32_t s_lds[TRAV_LDS_WORDS(STACK_LDS, PROP_BLOCK)];
+    if (*retry_counter == 0u) return;
+    LaneCounters cnt = {0, 0, 0, 0};
+    int stride = gridDim.x * PROP_BLOCK;
+    for (int base = blockIdx.x * PROP_BLOCK; base < nthreads; base += stride) {
+        int id = base + threadIdx.x;
+        bool cast = false;
+        v3 position = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
+        int last_hit = -1, slot = first_photon + id;
+        if (id < nthreads && hit_triangle[slot] == HIT_RETRY) {
+            uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
+            position = load3(pv.pos, photon_id);
+            direction = load3(pv.dir, photon_id);
+            direction = direction / norm(direction);
+            last_hit = pv.last_hit_triangles[photon_id];
+            cast = true;
+            if (COUNT) cnt.steps++;
+        }
+        if (!__any(cast)) continue;
+        float dist;
+        int found = intersect_mesh<STACK_LDS, PROP_BLOCK, COUNT>(g, position, direction, dist, last_hit, s_lds + threadIdx.x, cnt, cast);
+        if (cast) {
+            hit_triangle[slot] = found;
+            hit_distance[slot] = dist;
+        }
     }
     unsigned long long ov = wave_sum_u64(cnt.overflows);
     if (COUNT) {
@@ -521,13 +748,22 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     uint32_t need = geom->stack_need;
     if (need > STACK_LDS + STACK_SCRATCH)
         return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
-    dim3 grid((unsigned)((nthreads + PROP_BLOCK - 1) / PROP_BLOCK)), block(PROP_BLOCK);
-    if (ctx->counting)
-        hipLaunchKernelGGL((k_raycast<STACK_LDS, true>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->d_counters);
-    else
-        hipLaunchKernelGGL((k_raycast<STACK_LDS, false>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->d_counters);
+    // persistent ray cast: enough waves to fill the chip a few times over, each pulling rays
+    // from the queue through ctx->d_words[4]; d_words[5] counts the rays left for the retry pass
+    HIP_TRY(hipMemsetAsync(ctx->d_words + 4, 0, 8, ctx->stream));
+    unsigned waves = (unsigned)std::min<long long>(((long long)nthreads + PROP_BLOCK - 1) / PROP_BLOCK, (long long)ctx->persistent_waves);
+    dim3 grid(waves), block(PROP_BLOCK);
+    if (ctx->counting) {
+        hipLaunchKernelGGL((k_raycast_persistent<true>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 4, ctx->d_words + 5, ctx->d_counters);
+        hipLaunchKernelGGL((k_raycast_retry<true>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
+    } else {
+        hipLaunchKernelGGL((k_raycast_persistent<false>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 4, ctx->d_words + 5, ctx->d_counters);
+        hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
+    }
     hipLaunchKernelGGL(k_physics, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream, geom->view, pv, 0, nthreads,
                        in_q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first);
     HIP_TRY(hipGetLastError());
@@ -610,6 +846,13 @@ int chroma_init(int device, chroma_ctx **out)
     HIP_TRY(hipMalloc((void **)&ctx->d_words, 16 * sizeof(uint32_t)));
     HIP_TRY(hipMemset(ctx->d_words, 0, 16 * sizeof(uint32_t)));
     HIP_TRY(hipHostMalloc((void **)&ctx->h_words, 16 * sizeof(uint32_t), hipHostMallocDefault));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        int per_cu = 20;                     // LDS-limited residency of k_raycast_persistent (8 KB per wave)
+        if (const char *e = getenv("CHROMA_RAY_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));
+        ctx->persistent_waves = prop.multiProcessorCount * per_cu;
+    }
     HIP_TRY(hipEventCreate(&ctx->ev_start));
     HIP_TRY(hipEventCreate(&ctx->ev_stop));
     *out = ctx;
