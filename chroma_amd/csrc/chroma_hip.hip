@@ -449,7 +449,8 @@ k_raycast_retry(GeoView g, PhotonView pv, int first_photon, int nthreads, const 
     if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
 }
 
-__global__ __launch_bounds__(256) void
+#define PHYS_BLOCK 512
+__global__ __launch_bounds__(PHYS_BLOCK) void
 k_physics(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue, uint32_t *output_queue,
           const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base, int use_weights,
           int scatter_first)
@@ -495,7 +496,8 @@ k_physics(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32
             alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
         }
     }
-    if (output_queue) wave_queue_append(output_queue, alive, photon_id);
+    __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
+    if (output_queue) block_queue_append<PHYS_BLOCK / WAVE>(output_queue, alive, photon_id, s_counts);
 }
 
 // initial queue of GPUPhotons.propagate (chroma/gpu/photon.py:206-216): slot 0 unused counter,
@@ -549,13 +551,20 @@ __global__ void k_photon_duplicate(PhotonView pv, int first_photon, int nthreads
     for (int i = 1; i <= copies; i++) copy_photon(pv, photon_id, pv, photon_id + (size_t)stride * i);
 }
 
-// count_photons (propagate.cu:54-79): one atomic per wave
-__global__ void k_count_photons(const uint32_t *flags, int first_photon, int nthreads, uint32_t target_flag, uint32_t *counter)
+// count_photons (propagate.cu:54-79): grid-stride, one atomic per block
+__global__ __launch_bounds__(256) void
+k_count_photons(const uint32_t *flags, int first_photon, int nthreads, uint32_t target_flag, uint32_t *counter)
 {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    bool pred = (id < nthreads) && (flags[first_photon + id] & target_flag);
-    unsigned long long mask = __ballot(pred);
-    if (mask && lane_id() == (unsigned)__ffsll((long long)mask) - 1u) atomicAdd(counter, (uint32_t)__popcll(mask));
+    __shared__ uint32_t s_total;
+    if (threadIdx.x == 0) s_total = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nthreads; id += (long long)gridDim.x * blockDim.x)
+        mine += (flags[first_photon + id] & target_flag) != 0;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if (lane_id() == 0 && mine) atomicAdd(&s_total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_total) atomicAdd(counter, s_total);
 }
 
 __device__ inline uint32_t wave_reserve(uint32_t *counter, bool pred, bool &any)
@@ -598,15 +607,21 @@ __device__ inline int hit_channel(const GeoView &g, uint32_t history, int triang
     return g.solid_id_to_channel_index[solid_id];
 }
 
-// count_photon_hits (propagate.cu:147-174)
-__global__ void k_count_hits(GeoView g, const uint32_t *flags, const int32_t *last_hit, int first_photon, int nphotons,
-                             uint32_t detection_state, uint32_t *counter)
+// count_photon_hits (propagate.cu:147-174): grid-stride, one atomic per block
+__global__ __launch_bounds__(256) void
+k_count_hits(GeoView g, const uint32_t *flags, const int32_t *last_hit, int first_photon, int nphotons,
+             uint32_t detection_state, uint32_t *counter)
 {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    bool pred = false;
-    if (id < nphotons) pred = hit_channel(g, flags[first_photon + id], last_hit[first_photon + id], detection_state) >= 0;
-    unsigned long long mask = __ballot(pred);
-    if (mask && lane_id() == (unsigned)__ffsll((long long)mask) - 1u) atomicAdd(counter, (uint32_t)__popcll(mask));
+    __shared__ uint32_t s_total;
+    if (threadIdx.x == 0) s_total = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nphotons; id += (long long)gridDim.x * blockDim.x)
+        mine += hit_channel(g, flags[first_photon + id], last_hit[first_photon + id], detection_state) >= 0;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if (lane_id() == 0 && mine) atomicAdd(&s_total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_total) atomicAdd(counter, s_total);
 }
 
 // copy_photon_hits (propagate.cu:176-214)
@@ -764,7 +779,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
         hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
                            ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
     }
-    hipLaunchKernelGGL(k_physics, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream, geom->view, pv, 0, nthreads,
+    hipLaunchKernelGGL(k_physics, dim3((unsigned)((nthreads + PHYS_BLOCK - 1) / PHYS_BLOCK)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, 0, nthreads,
                        in_q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first);
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
@@ -1160,7 +1175,7 @@ int chroma_count_photons(chroma_ctx *ctx, int32_t first_photon, int32_t nthreads
     if (!ctx || !d_flags || !count) return set_error(CHROMA_ERR_INVALID, "bad argument");
     HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 4, ctx->stream));
     if (nthreads > 0) {
-        hipLaunchKernelGGL(k_count_photons, dim3((nthreads + 255) / 256), dim3(256), 0, ctx->stream, d_flags, first_photon,
+        hipLaunchKernelGGL(k_count_photons, dim3((unsigned)std::min((nthreads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, d_flags, first_photon,
                            nthreads, target_flag, ctx->d_words);
         HIP_TRY(hipGetLastError());
     }
@@ -1206,7 +1221,7 @@ int chroma_count_photon_hits(chroma_ctx *ctx, chroma_geometry *geom, int32_t fir
     int rc = check_photons(photons, false); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 4, ctx->stream));
     if (nphotons > 0) {
-        hipLaunchKernelGGL(k_count_hits, dim3((nphotons + 255) / 256), dim3(256), 0, ctx->stream, geom->view, photons->flags,
+        hipLaunchKernelGGL(k_count_hits, dim3((unsigned)std::min((nphotons + 255) / 256, 4096)), dim3(256), 0, ctx->stream, geom->view, photons->flags,
                            photons->last_hit_triangles, first_photon, nphotons, detection_state, ctx->d_words);
         HIP_TRY(hipGetLastError());
     }

@@ -95,6 +95,29 @@ __device__ inline void wave_queue_append(uint32_t *queue, bool pred, uint32_t va
     }
 }
 
+// Block-level variant: one atomic per BLOCK (a hot word takes only ~88 atomics/us, so one per
+// wave is too many for 1e8 photons).  Waves publish their counts in LDS, wave 0 reserves the
+// block's span, every lane then writes at its own offset.  All threads of the block must call it.
+template <int MAX_WAVES>
+__device__ inline void block_queue_append(uint32_t *queue, bool pred, uint32_t value, uint32_t *s_counts /* [MAX_WAVES+1] */)
+{
+    unsigned long long mask = __ballot(pred);
+    unsigned lane = lane_id();
+    unsigned wave = threadIdx.x / WAVE, nwaves = (blockDim.x + WAVE - 1) / WAVE;
+    if (lane == 0) s_counts[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (unsigned w = 0; w < nwaves; w++) { uint32_t c = s_counts[w]; s_counts[w] = total; total += c; }
+        s_counts[MAX_WAVES] = total ? atomicAdd(queue, total) : 0u;
+    }
+    __syncthreads();
+    if (pred) {
+        uint32_t base = s_counts[MAX_WAVES] + s_counts[wave];
+        queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+    }
+}
+
 __device__ inline unsigned long long wave_sum_u64(unsigned long long v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
