@@ -1,0 +1,89 @@
+"""The N > 1 path on the CPU: two ranks over gloo, each propagating its photon shard with the
+oracle (standing in for its GPU) and all-reducing the per-channel hit arrays with
+chroma_amd.dist -- the code bench.py runs over RCCL.  Because a photon's Philox stream is keyed
+by its GLOBAL id, the reduced result must equal the single-process result bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _channel_arrays(geo, end, nchannels):
+    from chroma_amd import event
+    det = (end.flags & event.SURFACE_DETECT) != 0
+    tri = end.last_hit_triangles
+    ok = det & (tri > -1)
+    chan = geo.solid_id_to_channel_index[geo.solid_id[tri[ok]]]
+    t = end.t[ok][chan >= 0]
+    chan = chan[chan >= 0]
+    counts = np.bincount(chan, minlength=nchannels).astype(np.uint32)
+    earliest = np.full(nchannels, 0x7f800000, dtype=np.uint32)
+    np.minimum.at(earliest, chan, t.view(np.uint32))
+    return counts, earliest
+
+
+def _worker(rank, world, port, nphotons, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import oracle
+    from chroma_amd import demo
+    from chroma_amd.dist import shard_range, allreduce_channel_hits
+    from chroma_amd.loader import create_geometry_from_obj
+    from chroma_amd.gpu.geometry import pack_geometry
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    geo = create_geometry_from_obj(demo.tiny())
+    pk = pack_geometry(geo)
+    lo, hi = shard_range(nphotons, rank, world)
+    photons = oracle.generate_bomb(hi - lo, seed=12345, id_base=lo)          # the shard's own photons
+    end, _, _ = oracle.propagate(pk, photons, seed=12345, photon_id_base=lo, max_steps=100)
+    counts, earliest = _channel_arrays(geo, end, geo.num_channels())
+    counts, earliest = allreduce_channel_hits(counts, earliest)
+    if rank == 0:
+        np.savez(os.path.join(outdir, 'reduced.npz'), counts=counts, earliest=earliest)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    from chroma_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= -(-n // world)
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_hit_reduction_equals_single_process(tmp_path, oracle_mod, tiny_geometry, tiny_packed):
+    torch = pytest.importorskip('torch')
+    import torch.multiprocessing as mp
+    nphotons = 30000
+    mp.spawn(_worker, args=(2, _free_port(), nphotons, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / 'reduced.npz')
+    photons = oracle_mod.generate_bomb(nphotons, seed=12345, id_base=0)
+    end, _, _ = oracle_mod.propagate(tiny_packed, photons, seed=12345, photon_id_base=0, max_steps=100, nthreads=4)
+    counts, earliest = _channel_arrays(tiny_geometry, end, tiny_geometry.num_channels())
+    assert counts.sum() > 100
+    assert np.array_equal(got['counts'].astype(np.uint32), counts)
+    assert np.array_equal(got['earliest'], earliest)
+
+
+def test_allreduce_without_process_group_is_identity():
+    pytest.importorskip('torch')
+    from chroma_amd.dist import allreduce_channel_hits
+    c = np.array([1, 2, 3], dtype=np.uint32)
+    e = np.array([0x7f800000, 5, 7], dtype=np.uint32)
+    c2, e2 = allreduce_channel_hits(c, e)
+    assert np.array_equal(c2, c) and np.array_equal(e2, e)
