@@ -185,15 +185,32 @@ def main():
     value = total_photons / elapsed
     kernel_s = stats['kernel_ms'] / 1e3
     launches = max(1, stats['launches'])
-    achieved = (bytes_per_photon * nphotons * args.steps) / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    log('timed: %.3f s for %d steps; propagate kernels %.3f s in %d launches (avg %.3f ms); hits/photon %.4f' % (
-        elapsed, args.steps, kernel_s, launches, 1e3 * kernel_s / launches, stats['hits'] / (nphotons * args.steps)))
+    path_achieved = (bytes_per_photon * nphotons * args.steps) / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    # dominant kernel: the ray cast (k_raycast_persistent + its retry pass).  Algorithmic bytes per
+    # photon step: 16 B per node visited + 48 B per triangle tested + 36 B ray state read + 8 B hit written
+    ray_s = stats['raycast_ms'] / 1e3
+    ray_launches = max(1, stats['raycast_launches'])
+    ray_bytes_per_step = 16.0 * nodes_ps + 48.0 * tris_ps + 36 + 8
+    ray_bytes_total = ray_bytes_per_step * steps_pp * nphotons * args.steps
+    achieved = ray_bytes_total / ray_s / 1e9 if ray_s > 0 else 0.0
+    log('timed: %.3f s for %d steps; propagate kernels %.3f s in %d launches, of which ray cast %.3f s in %d launches '
+        '(avg %.3f ms); hits/photon %.4f' % (elapsed, args.steps, kernel_s, launches, ray_s, ray_launches,
+                                             1e3 * ray_s / ray_launches, stats['hits'] / (nphotons * args.steps)))
+    # HBM traffic of the same command from rocprofv3 PMC passes (profiles/, corrected as calibrated there)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        key = '%s:%d:%d' % (args.config, nphotons, args.max_steps)
+        if key in pmc:
+            traffic = pmc[key]['hbm_bytes_per_launch']
+    except Exception:
+        pass
 
     cpu_baseline = None
     if packed_for_cpu is not None:
         import oracle
         cores = os.cpu_count() or 1
-        sample = args.cpu_sample or {'tiny': 400_000, 'lite': 400_000}.get(args.config, 1_000_000)
+        sample = args.cpu_sample or {'tiny': 400_000, 'lite': 1_000_000}.get(args.config, 3_000_000)
         ph = oracle.generate_bomb(sample, seed=ENGINE_SEED, id_base=0, wavelength_lo=wl_lo, wavelength_hi=wl_hi)
         t0 = time.perf_counter()
         end, _, ost = oracle.propagate(packed_for_cpu, ph, seed=ENGINE_SEED, photon_id_base=0, max_steps=args.max_steps, nthreads=cores)
@@ -222,10 +239,15 @@ def main():
                        'engine_seed': ENGINE_SEED, 'parallelism': 'photon shards x%d, geometry replicated' % world,
                        'steps_per_photon': steps_pp, 'nodes_per_step': nodes_ps, 'triangle_tests_per_step': tris_ps,
                        'geometry_build_s': t_build},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_propagate', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'algorithmic_bytes_per_photon': bytes_per_photon, 'launches': int(stats['launches']),
-                         'avg_launch_ms': 1e3 * kernel_s / launches, 'kernel_s': kernel_s},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_raycast_persistent', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': ray_bytes_total / ray_launches,
+                         'algorithmic_bytes_per_photon_step': ray_bytes_per_step,
+                         'launches': int(stats['raycast_launches']), 'avg_launch_ms': 1e3 * ray_s / ray_launches,
+                         'kernel_s': ray_s,
+                         'path': {'achieved': path_achieved, 'frac': path_achieved / HBM_PEAK_GBS,
+                                  'algorithmic_bytes_per_photon': bytes_per_photon, 'launches': int(stats['launches']),
+                                  'kernel_s': kernel_s}},
             'cpu_baseline': cpu_baseline,
         }
         print(json.dumps(result), flush=True)

@@ -53,7 +53,7 @@ struct chroma_ctx {
     uint32_t *h_words = nullptr;        // pinned mirror
     int counting = 0;
     int persistent_waves = 256 * 20 * 4;   // grid of the persistent ray-cast kernel (set from the device at init)
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
 };
 
 struct chroma_geometry {
@@ -757,7 +757,7 @@ static int launch_propagate(chroma_ctx *ctx, chroma_geometry *geom, PhotonView p
 
 // one step for many photons: ray cast and physics as two launches
 static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, int nthreads, const uint32_t *in_q,
-                             uint32_t *out_q, chroma_rng rng, int use_weights, int scatter_first)
+                             uint32_t *out_q, chroma_rng rng, int use_weights, int scatter_first, bool mark_raycast_end = false)
 {
     if (nthreads <= 0) return CHROMA_OK;
     uint32_t need = geom->stack_need;
@@ -779,6 +779,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
         hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
                            ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
     }
+    if (mark_raycast_end) HIP_TRY(hipEventRecord(ctx->ev_mid, ctx->stream));
     hipLaunchKernelGGL(k_physics, dim3((unsigned)((nthreads + PHYS_BLOCK - 1) / PHYS_BLOCK)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, 0, nthreads,
                        in_q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first);
     HIP_TRY(hipGetLastError());
@@ -870,6 +871,7 @@ int chroma_init(int device, chroma_ctx **out)
     }
     HIP_TRY(hipEventCreate(&ctx->ev_start));
     HIP_TRY(hipEventCreate(&ctx->ev_stop));
+    HIP_TRY(hipEventCreate(&ctx->ev_mid));
     *out = ctx;
     return CHROMA_OK;
 }
@@ -888,6 +890,7 @@ int chroma_shutdown(chroma_ctx *ctx)
     hipHostFree(ctx->h_words);
     hipEventDestroy(ctx->ev_start);
     hipEventDestroy(ctx->ev_stop);
+    hipEventDestroy(ctx->ev_mid);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return CHROMA_OK;
@@ -1326,8 +1329,8 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, out_q, 1u);
     HIP_TRY(hipGetLastError());
 
-    double kernel_ms = 0.0;
-    uint64_t launches = 0;
+    double kernel_ms = 0.0, raycast_ms = 0.0;
+    uint64_t launches = 0, raycast_launches = 0;
     uint64_t n = nphotons;
     int step = 0;
     while (step < max_steps) {
@@ -1335,7 +1338,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         int nsteps = (n < (uint64_t)PROP_BLOCK * 16 * 8 || use_weights) ? (max_steps - step) : 1;
         if (time_kernels) HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
         if (nsteps == 1)
-            rc = launch_split_step(ctx, geom, pv, (int)n, in_q + 1, out_q, rng, use_weights, scatter_first);
+            rc = launch_split_step(ctx, geom, pv, (int)n, in_q + 1, out_q, rng, use_weights, scatter_first, time_kernels != 0);
         else
             rc = launch_propagate(ctx, geom, pv, 0, (int)n, in_q + 1, out_q, rng, nsteps, use_weights, scatter_first);
         if (rc) return rc;
@@ -1346,6 +1349,11 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
             kernel_ms += ms;
+            if (nsteps == 1) {
+                HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_mid));
+                raycast_ms += ms;
+                raycast_launches++;
+            }
         }
         step += nsteps;
         scatter_first = 0;
@@ -1374,6 +1382,8 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         rc = chroma_propagate_stats_read(ctx, stats); if (rc) return rc;
         stats->launches += launches;
         stats->kernel_ms += kernel_ms;
+        stats->raycast_ms += raycast_ms;
+        stats->raycast_launches += raycast_launches;
         if (stats->stack_overflows) return set_error(CHROMA_ERR_STACK, "traversal stack overflowed for %llu rays", (unsigned long long)stats->stack_overflows);
     } else {
         chroma_propagate_stats tmp; memset(&tmp, 0, sizeof tmp);

@@ -153,6 +153,8 @@ typedef struct chroma_propagate_stats {
     uint64_t launches;           /* propagate kernel launches                                   */
     uint64_t stack_overflows;    /* rays whose traversal stack overflowed (must be 0)           */
     double   kernel_ms;          /* HIP-event time of the propagate kernel launches, if timed   */
+    double   raycast_ms;         /* of which: the ray-cast kernel (k_raycast_persistent)         */
+    uint64_t raycast_launches;   /* number of ray-cast launches timed in raycast_ms              */
 } chroma_propagate_stats;
 
 const char *chroma_last_error(void);
