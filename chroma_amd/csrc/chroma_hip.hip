@@ -61,6 +61,7 @@ struct chroma_geometry {
     GeoView view;
     std::vector<void *> allocations;
     void *d_vertices = nullptr, *d_triangles = nullptr, *d_material_codes = nullptr, *d_colors = nullptr;
+    void *d_nodes_api = nullptr;       // nodes exactly as passed in (GPUGeometry.nodes)
     size_t nvertices = 0, ntriangles = 0, nnodes = 0;
     uint32_t stack_need = 0;
     size_t device_bytes = 0;
@@ -295,6 +296,7 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, int nthreads, c
                                 if (COUNT) cnt.steps++;
                                 rf = ray_fast(g, noid, inv_dir);
                                 last_hit = pv.last_hit_triangles[photon_id];
+                                if (last_hit >= 0) last_hit = (int)g.tri_to_dev[last_hit];      // device index (leaf order)
                                 triangle_index = -1;
                                 min_distance = -1.0f;
                                 sp = 0;
@@ -386,7 +388,7 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, int nthreads, c
 
         // ---- retire finished rays
         if (has_ray && !active) {
-            hit_triangle[slot] = triangle_index;
+            hit_triangle[slot] = (triangle_index >= 0) ? (int)g.dev_to_tri[triangle_index] : triangle_index;
             hit_distance[slot] = min_distance;
             if (triangle_index == HIT_RETRY) atomicAdd(retry_counter, 1u);
             has_ray = false;
@@ -771,15 +773,16 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (ctx->counting) {
         hipLaunchKernelGGL((k_raycast_persistent<true>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
                            ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 4, ctx->d_words + 5, ctx->d_counters);
+        if (mark_raycast_end) HIP_TRY(hipEventRecord(ctx->ev_mid, ctx->stream));
         hipLaunchKernelGGL((k_raycast_retry<true>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
                            ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
     } else {
         hipLaunchKernelGGL((k_raycast_persistent<false>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
                            ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 4, ctx->d_words + 5, ctx->d_counters);
+        if (mark_raycast_end) HIP_TRY(hipEventRecord(ctx->ev_mid, ctx->stream));
         hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
                            ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
     }
-    if (mark_raycast_end) HIP_TRY(hipEventRecord(ctx->ev_mid, ctx->stream));
     hipLaunchKernelGGL(k_physics, dim3((unsigned)((nthreads + PHYS_BLOCK - 1) / PHYS_BLOCK)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, 0, nthreads,
                        in_q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first);
     HIP_TRY(hipGetLastError());
@@ -1019,9 +1022,51 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     memset(&v, 0, sizeof v);
     int rc;
 #define UP(field, src, count) if ((rc = upload(g, src, (size_t)(count), &v.field)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; }
-    // nodes
-    { const uint4 *p; if ((rc = upload(g, (const uint4 *)d->nodes, d->nnodes, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } v.nodes = p; }
-    // 48-byte triangle records, staged in chunks
+    // nodes as passed in (what GPUGeometry.nodes shows)
+    { const uint4 *p; if ((rc = upload(g, (const uint4 *)d->nodes, d->nnodes, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_nodes_api = (void *)p; }
+    // device triangle order = order of the leaf layer (the trailing run of leaf nodes), so that
+    // the triangles of sibling leaves share cache lines
+    std::vector<uint32_t> tri_to_dev(d->ntriangles, 0xFFFFFFFFu), dev_to_tri;
+    dev_to_tri.reserve(d->ntriangles);
+    {
+        size_t start = d->nnodes;
+        while (start > 0 && (d->nodes[4 * (start - 1) + 3] >> CHROMA_CHILD_BITS) == 0) start--;
+        auto take = [&](size_t i) {
+            uint32_t w = d->nodes[4 * i + 3];
+            if ((w >> CHROMA_CHILD_BITS) != 0) return;
+            uint32_t t = w & ~CHROMA_NCHILD_MASK;
+            if (tri_to_dev[t] == 0xFFFFFFFFu) { tri_to_dev[t] = (uint32_t)dev_to_tri.size(); dev_to_tri.push_back(t); }
+        };
+        for (size_t i = start; i < d->nnodes; i++) take(i);
+        for (size_t i = 0; i < start; i++) take(i);
+        for (uint32_t t = 0; t < d->ntriangles; t++)
+            if (tri_to_dev[t] == 0xFFFFFFFFu) { tri_to_dev[t] = (uint32_t)dev_to_tri.size(); dev_to_tri.push_back(t); }
+    }
+    UP(tri_to_dev, tri_to_dev.data(), tri_to_dev.size());
+    UP(dev_to_tri, dev_to_tri.data(), dev_to_tri.size());
+    // traversal copy of the nodes: leaf child -> device triangle index
+    {
+        void *dn = nullptr;
+        size_t bytes = (size_t)d->nnodes * 16;
+        hipError_t e = hipMalloc(&dn, bytes);
+        if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "hipMalloc(%zu) for nodes: %s", bytes, hipGetErrorString(e)); }
+        g->allocations.push_back(dn);
+        g->device_bytes += bytes;
+        const size_t CH = 1u << 22;
+        std::vector<uint32_t> stage(std::min((size_t)d->nnodes, CH) * 4);
+        for (size_t n0 = 0; n0 < d->nnodes; n0 += CH) {
+            size_t n1 = std::min((size_t)d->nnodes, n0 + CH);
+            memcpy(stage.data(), d->nodes + 4 * n0, (n1 - n0) * 16);
+            for (size_t i = 0; i < n1 - n0; i++) {
+                uint32_t w = stage[4 * i + 3];
+                if ((w >> CHROMA_CHILD_BITS) == 0) stage[4 * i + 3] = tri_to_dev[w & ~CHROMA_NCHILD_MASK];
+            }
+            e = hipMemcpy((char *)dn + n0 * 16, stage.data(), (n1 - n0) * 16, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "node upload: %s", hipGetErrorString(e)); }
+        }
+        v.nodes = (const uint4 *)dn;
+    }
+    // 48-byte triangle records in device order, staged in chunks
     {
         void *dtri = nullptr;
         size_t bytes = (size_t)d->ntriangles * 48;
@@ -1033,11 +1078,12 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
         std::vector<float> stage(std::min((size_t)d->ntriangles, CH) * 12);
         for (size_t t0 = 0; t0 < d->ntriangles; t0 += CH) {
             size_t t1 = std::min((size_t)d->ntriangles, t0 + CH);
-            for (size_t t = t0; t < t1; t++) {
-                float *r = stage.data() + (t - t0) * 12;
-                for (int k = 0; k < 3; k++) {
-                    const float *vv = d->vertices + 3 * (size_t)d->triangles[3 * t + k];
-                    r[4 * k] = vv[0]; r[4 * k + 1] = vv[1]; r[4 * k + 2] = vv[2];
+            for (size_t k = t0; k < t1; k++) {
+                size_t t = dev_to_tri[k];
+                float *r = stage.data() + (k - t0) * 12;
+                for (int c = 0; c < 3; c++) {
+                    const float *vv = d->vertices + 3 * (size_t)d->triangles[3 * t + c];
+                    r[4 * c] = vv[0]; r[4 * c + 1] = vv[1]; r[4 * c + 2] = vv[2];
                 }
                 uint32_t code = d->material_codes[t], sid = d->solid_id_map ? d->solid_id_map[t] : 0u, zero = 0u;
                 memcpy(&r[3], &code, 4); memcpy(&r[7], &sid, 4); memcpy(&r[11], &zero, 4);
@@ -1116,7 +1162,7 @@ int chroma_geometry_device_ptr(chroma_geometry *g, const char *name, void **d_pt
     if (!g || !name || !d_ptr) return set_error(CHROMA_ERR_INVALID, "bad argument");
     std::string n(name);
     size_t bytes = 0; void *p = nullptr;
-    if (n == "nodes") { p = (void *)g->view.nodes; bytes = g->nnodes * 16; }
+    if (n == "nodes") { p = g->d_nodes_api; bytes = g->nnodes * 16; }
     else if (n == "vertices") { p = g->d_vertices; bytes = g->nvertices * 12; }
     else if (n == "triangles") { p = g->d_triangles; bytes = g->ntriangles * 12; }
     else if (n == "material_codes") { p = g->d_material_codes; bytes = g->ntriangles * 4; }

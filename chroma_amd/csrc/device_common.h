@@ -39,13 +39,19 @@ __device__ inline void store3(float *p, size_t i, v3 v) { p[3 * i] = v.x; p[3 * 
 //   nodes   uint4[nnodes]            16 B packed node, as chroma/cuda/geometry_types.h:57-67
 //   tri     float4[ntriangles][3]    48 B record: v0.xyz|material_code, v1.xyz|solid_id, v2.xyz|0
 //                                    (one aligned 48-B gather instead of the reference's
-//                                     12-B index fetch + three 12-B vertex gathers)
+//                                     12-B index fetch + three 12-B vertex gathers).  Records are
+//                                    stored in LEAF order (the Morton order of the BVH's leaf layer),
+//                                    not in triangle-id order: the leaves under one parent -- tested
+//                                    together -- then sit in the same or adjacent 128-B lines.  The
+//                                    traversal's copy of the nodes holds that "device" index in its
+//                                    leaves; tri_to_dev / dev_to_tri translate at ray start and end.
 //   tables  float[...]               optics tables, row-major [row][wavelength_n]
 struct SurfaceInfo { uint32_t model; uint32_t transmissive; float thickness; int32_t dichroic_index; };
 
 struct GeoView {
-    const uint4  *nodes;
-    const float4 *tri;
+    const uint4  *nodes;             // traversal copy: leaf child = device triangle index
+    const float4 *tri;               // [device triangle index][3]
+    const uint32_t *tri_to_dev, *dev_to_tri;
     // materials
     const float *mat_refractive_index, *mat_absorption_length, *mat_scattering_length;
     const uint32_t *mat_num_comp, *mat_comp_offset;

@@ -280,14 +280,19 @@ __device__ inline int intersect_mesh(const GeoView &g, v3 origin, v3 direction, 
 {
     const v3 noid = (-origin) / direction;
     const v3 inv_dir = 1.0f / direction;
+    // the walk works on device triangle indices (leaf order, see device_common.h)
+    int last_hit_dev = (lane_on && last_hit_triangle >= 0) ? (int)g.tri_to_dev[last_hit_triangle] : -1;
+    int found;
     // |1/d| < 1e30 on all axes (false for inf and NaN): the whole wave takes the fast slab test
     bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
                     cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
     if (__any(lane_on && !moderate))
-        return intersect_mesh_walk<LDS_N, BLOCK, COUNT, false>(g, origin, direction, noid, inv_dir, min_distance,
-                                                               last_hit_triangle, lds, cnt, lane_on);
-    return intersect_mesh_walk<LDS_N, BLOCK, COUNT, true>(g, origin, direction, noid, inv_dir, min_distance,
-                                                          last_hit_triangle, lds, cnt, lane_on);
+        found = intersect_mesh_walk<LDS_N, BLOCK, COUNT, false>(g, origin, direction, noid, inv_dir, min_distance,
+                                                                last_hit_dev, lds, cnt, lane_on);
+    else
+        found = intersect_mesh_walk<LDS_N, BLOCK, COUNT, true>(g, origin, direction, noid, inv_dir, min_distance,
+                                                               last_hit_dev, lds, cnt, lane_on);
+    return (found >= 0) ? (int)g.dev_to_tri[found] : found;
 }
 
 // ---- random.h / interpolate.h -----------------------------------------------------------------
@@ -354,7 +359,7 @@ __device__ inline void apply_hit(State &s, Photon &p, const GeoView &g, int tria
         p.history |= CHROMA_NO_HIT;
         return;
     }
-    const float4 *t = g.tri + 3 * (size_t)triangle;
+    const float4 *t = g.tri + 3 * (size_t)g.tri_to_dev[triangle];
     float4 a = t[0], b = t[1], c = t[2];
     v3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(b.x, b.y, b.z), v2 = mk3(c.x, c.y, c.z);
     uint32_t material_code = __float_as_uint(a.w);
