@@ -74,6 +74,13 @@ class PropagateStats(Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class DaqTables(Structure):
+    """chroma_daq_tables"""
+    _fields_ = [('d_time_cdf_x', c_void_p), ('d_time_cdf_y', c_void_p), ('time_cdf_len', c_int32),
+                ('d_charge_cdf_x', c_void_p), ('d_charge_cdf_y', c_void_p), ('charge_cdf_len', c_int32),
+                ('charge_unit', c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/chroma_hip.h declares
 SIGNATURES = {
     'chroma_last_error': (c_char_p, []),
@@ -111,6 +118,10 @@ SIGNATURES = {
                                    c_int32, c_int32, c_int32, POINTER(PropagateStats), POINTER(c_int32)]),
     'chroma_channel_hits': (c_int32, [c_void_p, c_void_p, c_uint64, c_uint32, POINTER(PhotonArrays),
                                       c_void_p, c_void_p]),
+    'chroma_daq_reset': (c_int32, [c_void_p, c_float, c_uint32, c_void_p, c_void_p, c_void_p]),
+    'chroma_daq_acquire': (c_int32, [c_void_p, c_void_p, POINTER(DaqTables), c_int32, c_int32, c_uint32, POINTER(PhotonArrays),
+                                     Rng, c_uint32, c_float, c_void_p, c_void_p, c_void_p]),
+    'chroma_daq_convert': (c_int32, [c_void_p, c_uint32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'chroma_generate_bomb': (c_int32, [c_void_p, POINTER(PhotonArrays), c_uint64, c_uint64, c_uint64,
                                        POINTER(c_float), c_float, c_float]),
     'chroma_bvh_build': (c_int32, [c_void_p, c_uint32, c_void_p, c_uint32, POINTER(c_float), c_float, c_int32,

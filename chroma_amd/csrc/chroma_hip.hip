@@ -654,6 +654,70 @@ __global__ void k_channel_hits(GeoView g, const uint32_t *flags, const int32_t *
     }
 }
 
+// ---- DAQ (chroma/cuda/daq.cu) ------------------------------------------------------------------
+// interp (interpolate.h:32-57) as used by sample_cdf(rng, n, cdf_x, cdf_y) (random.h:26-31)
+__device__ inline float interp_table(float x, int n, const float *xp, const float *fp)
+{
+    int lower = 0;
+    int upper = n - 1;
+    if (x <= xp[lower]) return fp[lower];
+    if (x >= xp[upper]) return fp[upper];
+    while (lower < upper - 1) {
+        int half = (lower + upper) / 2;
+        if (x < xp[half]) upper = half; else lower = half;
+    }
+    float df = fp[upper] - fp[lower];
+    float dx = xp[upper] - xp[lower];
+    return fp[lower] + df * (x - xp[lower]) / dx;
+}
+
+__global__ void k_daq_reset(float maxtime, uint32_t n, uint32_t *time_ints, uint32_t *q_ints, uint32_t *histories)
+{
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < n) {
+        time_ints[id] = __float_as_uint(maxtime);
+        q_ints[id] = 0u;
+        histories[id] = 0u;
+    }
+}
+
+// run_daq (daq.cu:35-86)
+__global__ void k_run_daq(GeoView g, chroma_daq_tables tab, int first_photon, int nphotons, uint32_t detection_state,
+                          const float *photon_times, const uint32_t *photon_histories, const int32_t *last_hit_triangles,
+                          const float *weights, uint64_t seed, uint64_t id_base, uint32_t acquisition, float global_weight,
+                          uint32_t *earliest_time_int, uint32_t *channel_q_int, uint32_t *channel_histories)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nphotons) return;
+    int photon_id = id + first_photon;
+    int triangle_id = last_hit_triangles[photon_id];
+    if (triangle_id <= -1) return;
+    uint32_t history = photon_histories[photon_id];
+    int channel_index = g.solid_id_to_channel_index[g.solid_id_map[triangle_id]];
+    if (channel_index < 0 || !(history & detection_state)) return;
+    cm_rng rng;
+    cm_rng_init(&rng, seed, id_base + (uint64_t)photon_id, 0);
+    rng.stream = 1u + acquisition;
+    float weight = weights[photon_id] * global_weight;
+    if (cm_rng_uniform(&rng) < weight) {
+        float time = photon_times[photon_id] + interp_table(cm_rng_uniform(&rng), tab.time_cdf_len, tab.d_time_cdf_y, tab.d_time_cdf_x);
+        float charge = interp_table(cm_rng_uniform(&rng), tab.charge_cdf_len, tab.d_charge_cdf_y, tab.d_charge_cdf_x);
+        uint32_t charge_int = (uint32_t)cm_roundf(charge / tab.charge_unit);
+        atomicMin(earliest_time_int + channel_index, __float_as_uint(time));
+        atomicAdd(channel_q_int + channel_index, charge_int);
+        atomicOr(channel_histories + channel_index, history);
+    }
+}
+
+__global__ void k_daq_convert(uint32_t n, float charge_unit, const uint32_t *time_ints, const uint32_t *q_ints, float *t_out, float *q_out)
+{
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < n) {
+        t_out[id] = __uint_as_float(time_ints[id]);
+        q_out[id] = (float)q_ints[id] * charge_unit;
+    }
+}
+
 // distance_to_mesh (chroma/cuda/mesh.h:124-151)
 template <int LDS_N, bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
@@ -1449,6 +1513,50 @@ int chroma_channel_hits(chroma_ctx *ctx, chroma_geometry *geom, uint64_t nphoton
     hipLaunchKernelGGL(k_channel_hits, dim3((unsigned)((nphotons + 255) / 256)), dim3(256), 0, ctx->stream, geom->view,
                        photons->flags, photons->last_hit_triangles, photons->t, (uint64_t)nphotons, detection_state,
                        d_hit_count, d_earliest_time_bits);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+int chroma_daq_reset(chroma_ctx *ctx, float maxtime, uint32_t nchannels, uint32_t *d_earliest_time_int,
+                     uint32_t *d_channel_q_int, uint32_t *d_channel_histories)
+{
+    if (!ctx || !d_earliest_time_int || !d_channel_q_int || !d_channel_histories) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (nchannels == 0) return CHROMA_OK;
+    hipLaunchKernelGGL(k_daq_reset, dim3((nchannels + 255) / 256), dim3(256), 0, ctx->stream, maxtime, nchannels,
+                       d_earliest_time_int, d_channel_q_int, d_channel_histories);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+int chroma_daq_acquire(chroma_ctx *ctx, chroma_geometry *geom, const chroma_daq_tables *tables, int32_t first_photon,
+                       int32_t nphotons, uint32_t detection_state, const chroma_photon_arrays *photons, chroma_rng rng,
+                       uint32_t acquisition, float global_weight, uint32_t *d_earliest_time_int,
+                       uint32_t *d_channel_q_int, uint32_t *d_channel_histories)
+{
+    if (!ctx || !geom || !tables || !d_earliest_time_int || !d_channel_q_int || !d_channel_histories)
+        return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (!geom->view.nsolids) return set_error(CHROMA_ERR_INVALID, "geometry has no detector channel map");
+    if (tables->time_cdf_len < 2 || tables->charge_cdf_len < 2 || !tables->d_time_cdf_x || !tables->d_time_cdf_y ||
+        !tables->d_charge_cdf_x || !tables->d_charge_cdf_y || !(tables->charge_unit > 0.0f))
+        return set_error(CHROMA_ERR_INVALID, "DAQ tables: need two CDFs of at least 2 points and a positive charge unit");
+    int rc = check_photons(photons, false); if (rc) return rc;
+    if (nphotons <= 0) return CHROMA_OK;
+    hipLaunchKernelGGL(k_run_daq, dim3((nphotons + 255) / 256), dim3(256), 0, ctx->stream, geom->view, *tables, first_photon,
+                       nphotons, detection_state, photons->t, photons->flags, photons->last_hit_triangles, photons->weights,
+                       rng.seed, rng.photon_id_base, acquisition, global_weight, d_earliest_time_int, d_channel_q_int,
+                       d_channel_histories);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+int chroma_daq_convert(chroma_ctx *ctx, uint32_t nchannels, float charge_unit, const uint32_t *d_earliest_time_int,
+                       const uint32_t *d_channel_q_int, float *d_earliest_time, float *d_channel_q)
+{
+    if (!ctx || !d_earliest_time_int || !d_channel_q_int || !d_earliest_time || !d_channel_q)
+        return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (nchannels == 0) return CHROMA_OK;
+    hipLaunchKernelGGL(k_daq_convert, dim3((nchannels + 255) / 256), dim3(256), 0, ctx->stream, nchannels, charge_unit,
+                       d_earliest_time_int, d_channel_q_int, d_earliest_time, d_channel_q);
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
 }

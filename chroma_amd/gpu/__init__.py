@@ -5,3 +5,4 @@ from chroma_amd.gpu.tools import (create_cuda_context, get_context, get_rng_stat
 from chroma_amd.gpu.geometry import GPUGeometry, pack_geometry
 from chroma_amd.gpu.detector import GPUDetector
 from chroma_amd.gpu.photon import GPUPhotons, GPUPhotonsSlice
+from chroma_amd.gpu.daq import GPUDaq, GPUChannels

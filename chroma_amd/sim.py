@@ -3,7 +3,7 @@
 Reference: chroma/sim.py:21-186 (``Simulation.__init__``, ``_simulate_batch``, ``simulate``).
 Out of scope here, as in SURVEY.md section 8: GEANT4 photon generation (``geant4_processes``
 is accepted; Event/Vertex inputs need a generator that this package does not provide), the
-PDF / likelihood entry points and the DAQ (``run_daq``).
+PDF / likelihood entry points.
 """
 import os
 import time
@@ -37,6 +37,7 @@ class Simulation(object):
             detector.bvh = load_bvh(detector)
         if hasattr(detector, 'num_channels'):
             self.gpu_geometry = gpu.GPUDetector(detector)
+            self.gpu_daq = gpu.GPUDaq(self.gpu_geometry)
         else:
             self.gpu_geometry = gpu.GPUGeometry(detector)
         self.rng_states = gpu.get_rng_states(self.nthreads_per_block * self.max_blocks, seed=self.seed)
@@ -60,8 +61,6 @@ class Simulation(object):
             print('GPU copy took %0.2f s' % (t_copy - t_start))
             print('GPU propagate took %0.2f s' % (t_prop - t_copy))
 
-        if run_daq:
-            raise NotImplementedError('the DAQ (chroma/gpu/daq.py) is not part of this engine yet')
         is_detector = hasattr(self.detector, 'num_channels')
         batch_end = gpu_photons.get() if keep_photons_end else None
         batch_hits = gpu_photons.get_flat_hits(self.gpu_geometry) if is_detector and (keep_hits or keep_flat_hits) else None
@@ -90,6 +89,12 @@ class Simulation(object):
                     ev.hits = {int(ch): ev_hits[ev_hits.channel == ch] for ch in np.unique(ev_hits.channel)}
                 if keep_flat_hits:
                     ev.flat_hits = ev_hits
+            if hasattr(self, 'gpu_daq') and run_daq:
+                # one acquisition per event, as the reference (chroma/sim.py:128-137)
+                self.gpu_daq.begin_acquire()
+                self.gpu_daq.acquire(gpu_photons, self.rng_states, start_photon=int(lo), nphotons=int(hi - lo),
+                                     nthreads_per_block=self.nthreads_per_block, max_blocks=self.max_blocks)
+                ev.channels = self.gpu_daq.end_acquire().get()
             yield ev
 
     def simulate(self, iterable, keep_photons_beg=False, keep_photons_end=False, keep_hits=True,

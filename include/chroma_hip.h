@@ -249,6 +249,32 @@ int chroma_channel_hits(chroma_ctx *ctx, chroma_geometry *geom, uint64_t nphoton
                         uint32_t detection_state, const chroma_photon_arrays *photons,
                         uint32_t *d_hit_count, uint32_t *d_earliest_time_bits);
 
+/* ---- DAQ --------------------------------------------------------
+ * `run_daq` (chroma/cuda/daq.cu:35-86) for photons [first_photon, first_photon + nphotons): a
+ * photon with `detection_state` set whose last hit triangle belongs to a channel contributes, with
+ * probability weight * global_weight, a hit time (photon time + a draw from the time CDF) and a
+ * charge (a draw from the charge CDF, quantised to charge_unit) to its channel: atomicMin on the
+ * time bits, atomicAdd on the integer charge, atomicOr on the history.  The three draws come from
+ * the photon's Philox stream number 1 + acquisition (include/chroma_math.h), not from per-thread
+ * curandStates.  The CDF tables are DEVICE arrays of cdf_len floats each (chroma/cuda/detector.h).
+ * The channel arrays are accumulated into: reset them first (chroma_daq_reset). */
+typedef struct chroma_daq_tables {
+    const float *d_time_cdf_x, *d_time_cdf_y;      int32_t time_cdf_len;
+    const float *d_charge_cdf_x, *d_charge_cdf_y;  int32_t charge_cdf_len;
+    float charge_unit;
+} chroma_daq_tables;
+/* `reset_earliest_time_int` (daq.cu:25-33) + zeroing of charge and history */
+int chroma_daq_reset(chroma_ctx *ctx, float maxtime, uint32_t nchannels, uint32_t *d_earliest_time_int,
+                     uint32_t *d_channel_q_int, uint32_t *d_channel_histories);
+int chroma_daq_acquire(chroma_ctx *ctx, chroma_geometry *geom, const chroma_daq_tables *tables,
+                       int32_t first_photon, int32_t nphotons, uint32_t detection_state,
+                       const chroma_photon_arrays *photons, chroma_rng rng, uint32_t acquisition,
+                       float global_weight, uint32_t *d_earliest_time_int, uint32_t *d_channel_q_int,
+                       uint32_t *d_channel_histories);
+/* `convert_sortable_int_to_float` + `convert_charge_int_to_float` (daq.cu:152-173) */
+int chroma_daq_convert(chroma_ctx *ctx, uint32_t nchannels, float charge_unit, const uint32_t *d_earliest_time_int,
+                       const uint32_t *d_channel_q_int, float *d_earliest_time, float *d_channel_q);
+
 /* Isotropic photon bomb generated on the device (the benchmark source of
  * chroma/benchmark.py:77-83, formulas chroma/sample.py:16-30), photon i drawn from
  * Philox stream (seed, 0xB0B0000000000000 + id_base + i).  wavelength_hi <= wavelength_lo

@@ -50,6 +50,7 @@ CM_FN float cm_fmaxf(float a, float b) { if (cm_isnan(a)) return b; if (cm_isnan
 
 CM_FN float cm_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 CM_FN float cm_sqrtf(float x) { return __builtin_sqrtf(x); }
+CM_FN float cm_roundf(float x) { return __builtin_roundf(x); }   /* half away from zero, exact */
 
 /* ---- logf ------------------------------------------------------------- */
 CM_FN float cm_logf(float x)
@@ -297,7 +298,8 @@ CM_FN float cm_atan2f(float y, float x)
 
 /* ---- Philox4x32-10 (Salmon et al., SC'11; the generator cuRAND and rocRAND
  * expose as PHILOX4_32_10).  Key = (seed_lo, seed_hi); counter =
- * (block, 0, photon_id_lo, photon_id_hi).  Draw k of a photon is word (k & 3)
+ * (block, stream, photon_id_lo, photon_id_hi); stream 0 is the propagation stream, 1 + k the
+ * k-th DAQ acquisition.  Draw k of a photon is word (k & 3)
  * of block (k >> 2).  This replaces the reference's one-XORWOW-state-per-
  * thread-slot scheme (chroma/gpu/tools.py:56-84, chroma/cuda/propagate.cu:241,303)
  * with a per-photon stream, see SURVEY.md fact 3. */
@@ -335,6 +337,7 @@ typedef struct {
     uint32_t key0, key1;     /* seed */
     uint32_t id0, id1;       /* global photon id */
     uint32_t counter;        /* number of draws already taken */
+    uint32_t stream;         /* Philox counter word 1: 0 = propagation, 1 + k = k-th DAQ acquisition */
     uint32_t buf[4];         /* current block */
     uint32_t buf_block;      /* block index held in buf, 0xffffffff = none */
 } cm_rng;
@@ -344,6 +347,7 @@ CM_FN void cm_rng_init(cm_rng *r, uint64_t seed, uint64_t photon_id, uint32_t co
     r->key0 = (uint32_t)seed; r->key1 = (uint32_t)(seed >> 32);
     r->id0 = (uint32_t)photon_id; r->id1 = (uint32_t)(photon_id >> 32);
     r->counter = counter;
+    r->stream = 0u;
     r->buf_block = 0xffffffffu;
     r->buf[0] = r->buf[1] = r->buf[2] = r->buf[3] = 0u;
 }
@@ -352,7 +356,7 @@ CM_FN float cm_rng_uniform(cm_rng *r)
 {
     uint32_t blk = r->counter >> 2;
     if (blk != r->buf_block) {
-        cm_philox4x32_10(blk, 0u, r->id0, r->id1, r->key0, r->key1, r->buf);
+        cm_philox4x32_10(blk, r->stream, r->id0, r->id1, r->key0, r->key1, r->buf);
         r->buf_block = blk;
     }
     uint32_t lane = r->counter & 3u;

@@ -1039,6 +1039,51 @@ int oracle_distance_to_mesh(const chroma_geometry_desc *g, uint64_t n, const flo
     return 0;
 }
 
+/* ---- DAQ: run_daq (chroma/cuda/daq.cu:35-86) with interp (interpolate.h:32-57) -------------- */
+static float interp_table(float x, int n, const float *xp, const float *fp)
+{
+    int lower = 0;
+    int upper = n - 1;
+    if (x <= xp[lower]) return fp[lower];
+    if (x >= xp[upper]) return fp[upper];
+    while (lower < upper - 1) {
+        int half = (lower + upper) / 2;
+        if (x < xp[half]) upper = half; else lower = half;
+    }
+    float df = fp[upper] - fp[lower];
+    float dx = xp[upper] - xp[lower];
+    return fp[lower] + df * (x - xp[lower]) / dx;
+}
+
+/* Channel arrays are HOST arrays of nchannels entries, accumulated into (min / add / or). */
+int oracle_run_daq(const chroma_geometry_desc *g, const chroma_daq_tables *tab, int32_t first_photon, int32_t nphotons,
+                   uint32_t detection_state, const chroma_photon_arrays *a, chroma_rng rng_desc, uint32_t acquisition,
+                   float global_weight, uint32_t *earliest_time_int, uint32_t *channel_q_int, uint32_t *channel_histories)
+{
+    for (int id = 0; id < nphotons; id++) {
+        int photon_id = id + first_photon;
+        int triangle_id = a->last_hit_triangles[photon_id];
+        if (triangle_id <= -1) continue;
+        uint32_t history = a->flags[photon_id];
+        int channel_index = g->solid_id_to_channel_index[g->solid_id_map[triangle_id]];
+        if (channel_index < 0 || !(history & detection_state)) continue;
+        cm_rng rng;
+        cm_rng_init(&rng, rng_desc.seed, rng_desc.photon_id_base + (uint64_t)photon_id, 0);
+        rng.stream = 1u + acquisition;
+        float weight = a->weights[photon_id] * global_weight;
+        if (rng_u(&rng) < weight) {
+            float time = a->t[photon_id] + interp_table(rng_u(&rng), tab->time_cdf_len, tab->d_time_cdf_y, tab->d_time_cdf_x);
+            float charge = interp_table(rng_u(&rng), tab->charge_cdf_len, tab->d_charge_cdf_y, tab->d_charge_cdf_x);
+            uint32_t charge_int = (uint32_t)cm_roundf(charge / tab->charge_unit);
+            uint32_t time_int = cm_f2u(time);
+            if (time_int < earliest_time_int[channel_index]) earliest_time_int[channel_index] = time_int;
+            channel_q_int[channel_index] += charge_int;
+            channel_histories[channel_index] |= history;
+        }
+    }
+    return 0;
+}
+
 /* Isotropic photon bomb, the benchmark source of chroma/benchmark.py:77-83 with the
  * formulas of chroma/sample.py:16-30 in single precision; photon i is drawn from the Philox
  * stream (seed, 0xB0B0000000000000 + id_base + i): dir = uniform_sphere (2 draws), an auxiliary

@@ -269,3 +269,53 @@ def test_simulation_batching_and_per_event_split(gpu, tiny_geometry):
         assert len(ev.flat_hits) <= det.sum()
         assert sum(len(v) for v in ev.hits.values()) == len(ev.flat_hits)
         assert (ev.flat_hits.flags & event.SURFACE_DETECT != 0).all()
+
+
+def test_daq_matches_oracle_and_reference_test(gpu, oracle_mod, tiny_geometry, tiny_packed):
+    """GPUDaq (chroma/gpu/daq.py + cuda/daq.cu) against the oracle's run_daq, bit for bit, and the
+    intent of the reference's test/test_detector.py (time spread 1.2 ns, unit charge +- 0.1)."""
+    from chroma_amd.gpu.geometry import pack_geometry
+    ph = oracle_mod.generate_bomb(60000, seed=31)
+    ph.t[:] = 100.0
+    gg = gpu.GPUDetector(tiny_geometry)
+    rng_states = gpu.get_rng_states(64, seed=9)
+    gp = gpu.GPUPhotons(ph)
+    gp.propagate(gg, rng_states, max_steps=100)
+    end = gp.get()
+    daq = gpu.GPUDaq(gg)
+    for acquisition in range(2):
+        daq.begin_acquire()
+        daq.acquire(gp, rng_states)
+        ch = daq.end_acquire().get()
+        t, q, hist, hit = oracle_mod.run_daq(tiny_packed, end, daq._tables_host, daq.charge_unit, seed=9, acquisition=acquisition)
+        assert hit.sum() > 10 and np.array_equal(ch.hit, hit)
+        assert np.array_equal(ch.t.view(np.uint32), t.view(np.uint32))
+        assert np.array_equal(ch.q.view(np.uint32), q.view(np.uint32))
+        assert np.array_equal(ch.flags, hist)
+        if acquisition == 0:
+            first = ch.t.copy()
+    assert not np.array_equal(first, ch.t)                 # a new acquisition draws new smearing
+
+    # test/test_detector.py: one photocathode box, single-photon events through Simulation(run_daq=True)
+    from chroma_amd.sim import Simulation
+    from chroma_amd.detector import Detector
+    from chroma_amd.geometry import Solid, vacuum
+    from chroma_amd.make import box
+    from chroma_amd.demo.optics import r7081hqe_photocathode
+    from chroma_amd.loader import create_geometry_from_obj
+    cube = Detector(vacuum)
+    cube.add_pmt(Solid(box(10.0, 10, 10), vacuum, vacuum, surface=r7081hqe_photocathode))
+    cube.set_time_dist_gaussian(1.2, -6.0, 6.0)
+    cube.set_charge_dist_gaussian(1.0, 0.1, 0.5, 1.5)
+    sim = Simulation(create_geometry_from_obj(cube), geant4_processes=0, seed=4)
+    n = 1
+    photons = Photons(np.zeros((n, 3)), np.tile([0, 0, 1.0], (n, 1)), np.tile([1.0, 0, 0], (n, 1)), np.full(n, 400.0),
+                      t=np.full(n, 100.0))
+    times, charges = [], []
+    for ev in sim.simulate((photons for _ in range(1500)), run_daq=True, max_steps=10):
+        if ev.channels.hit[0]:
+            times.append(ev.channels.t[0])
+            charges.append(ev.channels.q[0])
+    assert len(times) > 200
+    assert abs(np.std(times) - 1.2) < 0.15
+    assert abs(np.mean(charges) - 1.0) < 0.1 and np.std(charges) < 0.2

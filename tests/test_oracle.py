@@ -138,3 +138,37 @@ def test_ray_cast_basics(oracle_mod, vacuum_box):
     assert np.allclose(dist, 50.0) and (tri >= 0).all()
     dist, tri, _ = oracle_mod.distance_to_mesh(vacuum_box, o + np.float32(200.0), d[:1])   # outside, pointing away
     assert tri[0] == -1 and np.isnan(dist[0])
+
+
+def test_daq_oracle_time_and_charge_spread(oracle_mod):
+    """Intent of the reference's test/test_detector.py on the CPU: a detected photon's channel time is
+    smeared by the time CDF (1.2 ns here) and its charge follows the charge CDF (1.0 +- 0.1)."""
+    from chroma_amd.detector import Detector
+    from chroma_amd.geometry import Solid, vacuum
+    from chroma_amd.make import box
+    from chroma_amd.demo.optics import r7081hqe_photocathode
+    from chroma_amd.loader import create_geometry_from_obj
+    from chroma_amd.gpu.daq import _padded_cdf
+    cube = Detector(vacuum)
+    cube.add_pmt(Solid(box(10.0, 10, 10), vacuum, vacuum, surface=r7081hqe_photocathode))
+    cube.set_time_dist_gaussian(1.2, -6.0, 6.0)
+    cube.set_charge_dist_gaussian(1.0, 0.1, 0.5, 1.5)
+    geo = create_geometry_from_obj(cube)
+    pk = pack_geometry(geo)
+    n = 4000
+    ph = Photons(np.zeros((n, 3)), np.tile([0, 0, 1.0], (n, 1)), np.tile([1.0, 0, 0], (n, 1)), np.full(n, 400.0), t=np.full(n, 100.0))
+    end, _, _ = oracle_mod.propagate(pk, ph, seed=2, max_steps=10)
+    detected = np.flatnonzero(end.flags & event.SURFACE_DETECT)
+    assert len(detected) > 800                          # QE 31.8 % at 400 nm
+    tables = _padded_cdf(*geo.time_cdf) + _padded_cdf(*geo.charge_cdf)
+    unit = np.float32(geo.charge_cdf[0][-1] / 2 ** 16)
+    times, charges = [], []
+    for i in detected[:800]:                            # one photon per acquisition: the channel's min is that photon's time
+        t, q, hist, hit = oracle_mod.run_daq(pk, end, tables, unit, seed=2, start_photon=int(i), nphotons=1)
+        assert hit[0] and hist[0] == end.flags[i]
+        times.append(t[0]); charges.append(q[0])
+    assert abs(np.std(times) - 1.2) < 0.15 and abs(np.mean(times) - end.t[detected[0]]) < 0.4
+    assert abs(np.mean(charges) - 1.0) < 0.05 and 0.05 < np.std(charges) < 0.2
+    # nothing detected -> nothing hit; weight 0 -> nothing hit
+    t, q, hist, hit = oracle_mod.run_daq(pk, end, tables, unit, seed=2, weight=0.0)
+    assert not hit.any() and q.sum() == 0
