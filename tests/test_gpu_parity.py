@@ -319,3 +319,13 @@ def test_daq_matches_oracle_and_reference_test(gpu, oracle_mod, tiny_geometry, t
     assert len(times) > 200
     assert abs(np.std(times) - 1.2) < 0.15
     assert abs(np.mean(charges) - 1.0) < 0.1 and np.std(charges) < 0.2
+
+
+def test_reference_benchmark_harness(gpu, tiny_geometry):
+    """chroma/benchmark.py's intersect / load_photons / propagate run and return sane rates."""
+    from chroma_amd import benchmark
+    gg = gpu.GPUDetector(tiny_geometry)
+    for fn, args in ((benchmark.intersect, (gg, 3, 100000)), (benchmark.load_photons, (3, 100000)),
+                     (benchmark.propagate, (gg, 3, 100000))):
+        mean, std = fn(*args)
+        assert mean > 1e5 and std >= 0
