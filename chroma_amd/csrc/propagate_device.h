@@ -530,7 +530,7 @@ __device__ inline int propagate_to_boundary(Photon &p, State &s, cm_rng &rng, co
 }
 
 // propagate_at_boundary (photon.h:310-363): Fresnel reflection / refraction
-__device__ __noinline__ void propagate_at_boundary(Photon &p, State &s, cm_rng &rng)
+__device__ inline void propagate_at_boundary(Photon &p, State &s, cm_rng &rng)
 {
     float incident_angle = get_theta(s.surface_normal, -p.direction);
     float refracted_angle = cm_asinf(cm_sinf(incident_angle) * s.refractive_index1 / s.refractive_index2);
@@ -634,7 +634,7 @@ __device__ inline cxf cx_sqrt(cxf a)
 
 struct RT { float r, t; };
 // reflectance / transmittance of the film for one polarisation (photon.h:440-458 and twins)
-__device__ __noinline__ RT film_rt(cxf r12, cxf r23, cxf t12, cxf t23, cxf gg, float u, float v, float e)
+__device__ inline RT film_rt(cxf r12, cxf r23, cxf t12, cxf t23, cxf gg, float u, float v, float e)
 {
     float abs_r12 = cx_abs(r12), abs_r23 = cx_abs(r23);
     float abs_t12 = cx_abs(t12), abs_t23 = cx_abs(t23);
@@ -652,7 +652,7 @@ __device__ __noinline__ RT film_rt(cxf r12, cxf r23, cxf t12, cxf t23, cxf gg, f
 }
 
 // propagate_complex (photon.h:400-590): thin-film surface
-__device__ __noinline__ int propagate_complex(Photon &p, State &s, cm_rng &rng, const GeoView &g, int si, bool use_weights)
+__device__ inline int propagate_complex(Photon &p, State &s, cm_rng &rng, const GeoView &g, int si, bool use_weights)
 {
     float detect = interp_property(g, p.wavelength, row(g.surf_detect, g, si));
     float reflect_diffuse = interp_property(g, p.wavelength, row(g.surf_reflect_diffuse, g, si));
@@ -758,7 +758,7 @@ __device__ __noinline__ int propagate_complex(Photon &p, State &s, cm_rng &rng, 
 }
 
 // propagate_at_wls (photon.h:592-637)
-__device__ __noinline__ int propagate_at_wls(Photon &p, State &s, cm_rng &rng, const GeoView &g, int si, bool use_weights)
+__device__ inline int propagate_at_wls(Photon &p, State &s, cm_rng &rng, const GeoView &g, int si, bool use_weights)
 {
     float absorb = interp_property(g, p.wavelength, row(g.surf_absorb, g, si));
     float reflect_specular = interp_property(g, p.wavelength, row(g.surf_reflect_specular, g, si));
@@ -802,7 +802,7 @@ __device__ __noinline__ int propagate_at_wls(Photon &p, State &s, cm_rng &rng, c
 }
 
 // propagate_at_dichroic (photon.h:640-670)
-__device__ __noinline__ int propagate_at_dichroic(Photon &p, State &s, cm_rng &rng, const GeoView &g, int si)
+__device__ inline int propagate_at_dichroic(Photon &p, State &s, cm_rng &rng, const GeoView &g, int si)
 {
     float incident_angle = get_theta(s.surface_normal, -p.direction);
     int di = g.surf_info[si].dichroic_index;
