@@ -2,24 +2,44 @@
 
 ``load_bvh`` (chroma/loader.py:131-160) in the reference needs a CUDA context because its
 BVH builder runs on the GPU; here the builder is host code, so no device is touched.
-The on-disk cache of the reference (pickles under ~/.chroma) is not reproduced yet.
+BVHs are cached as .npz files (chroma_amd/cache.py) when a ``cache_dir`` is given; unlike the
+reference the cache is OFF by default, because a build takes seconds.
+``load_geometry_from_string`` resolves the "@module.function" form of chroma/loader.py:90-112.
 """
+import importlib
+
 from chroma_amd.bvh import make_recursive_grid_bvh
 from chroma_amd.log import logger
 
 
 def load_bvh(geometry, bvh_name="default", auto_build_bvh=True, read_bvh_cache=True,
              update_bvh_cache=True, cache_dir=None, cuda_device=None, target_degree=3):
-    """Attach a BVH to a flattened geometry and return it."""
+    """Return a BVH for a flattened geometry: from the cache if present, otherwise built (and
+    cached when ``update_bvh_cache`` and a ``cache_dir`` are given)."""
     if not hasattr(geometry, 'mesh'):
         geometry.flatten()
+    cache = None
+    mesh_hash = None
+    if cache_dir is not None:
+        from chroma_amd.cache import Cache
+        cache = Cache(cache_dir)
+        mesh_hash = geometry.mesh.md5()
+        if read_bvh_cache and cache.exist_bvh(mesh_hash, bvh_name):
+            logger.info('Loading BVH "%s" from cache.' % bvh_name)
+            return cache.load_bvh(mesh_hash, bvh_name)
+    if not auto_build_bvh:
+        raise Exception('BVH "%s" not found in cache and auto_build_bvh is off' % bvh_name)
     logger.info('Building new BVH using recursive grid algorithm.')
-    return make_recursive_grid_bvh(geometry.mesh, target_degree=target_degree)
+    bvh = make_recursive_grid_bvh(geometry.mesh, target_degree=target_degree)
+    if cache is not None and update_bvh_cache:
+        logger.info('Saving BVH (%s:%s) to cache.' % (mesh_hash, bvh_name))
+        cache.save_bvh(bvh, mesh_hash, bvh_name)
+    return bvh
 
 
 def create_geometry_from_obj(obj, bvh_name="default", auto_build_bvh=True, read_bvh_cache=True,
                              update_bvh_cache=True, cache_dir=None, cuda_device=None):
-    """Flatten a Geometry/Detector (or wrap a Solid/Mesh in one) and build its BVH
+    """Flatten a Geometry/Detector (or wrap a Solid/Mesh in one) and attach its BVH
     (chroma/loader.py:46-88)."""
     from chroma_amd.geometry import Geometry, Solid, Mesh, vacuum
     if isinstance(obj, Geometry):
@@ -34,5 +54,19 @@ def create_geometry_from_obj(obj, bvh_name="default", auto_build_bvh=True, read_
         raise TypeError('cannot build a geometry from %r' % type(obj))
     geometry.flatten()
     if geometry.bvh is None:
-        geometry.bvh = load_bvh(geometry, auto_build_bvh=auto_build_bvh)
+        geometry.bvh = load_bvh(geometry, bvh_name=bvh_name, auto_build_bvh=auto_build_bvh, read_bvh_cache=read_bvh_cache,
+                                update_bvh_cache=update_bvh_cache, cache_dir=cache_dir)
     return geometry
+
+
+def load_geometry_from_string(geometry_str, auto_build_bvh=True, read_bvh_cache=True, update_bvh_cache=True,
+                              cache_dir=None, cuda_device=None):
+    """"@module.function[:bvh_name]" -> flattened geometry with BVH (chroma/loader.py:90-112).  The
+    function is called without arguments and must return a Geometry, Solid or Mesh."""
+    if not geometry_str.startswith('@'):
+        raise ValueError('only the "@module.function" form is supported (no STL files or named cache entries)')
+    name, _, bvh_name = geometry_str[1:].partition(':')
+    module_name, _, function_name = name.rpartition('.')
+    obj = getattr(importlib.import_module(module_name), function_name)()
+    return create_geometry_from_obj(obj, bvh_name=bvh_name or 'default', auto_build_bvh=auto_build_bvh,
+                                    read_bvh_cache=read_bvh_cache, update_bvh_cache=update_bvh_cache, cache_dir=cache_dir)
