@@ -329,3 +329,16 @@ def test_reference_benchmark_harness(gpu, tiny_geometry):
                      (benchmark.propagate, (gg, 3, 100000))):
         mean, std = fn(*args)
         assert mean > 1e5 and std >= 0
+
+
+def test_chroma_sim_driver(gpu, tmp_path):
+    """bin/chroma-sim: detector string -> events -> npz with flat hits and DAQ channels."""
+    from chroma_amd.cli import main
+    out = tmp_path / 'hits.npz'
+    assert main(['@chroma_amd.demo.tiny', '-n', '3', '--nphotons', '20000', '-s', '7', '--run-daq', '-o', str(out)]) == 0
+    f = np.load(out)
+    assert int(f['nevents']) == 3
+    for i in range(3):
+        ch = f['ev%d/channel' % i]
+        assert len(ch) > 50 and ch.max() < 53 and len(f['ev%d/t' % i]) == len(ch)
+        assert f['ev%d/daq_hit' % i].sum() == len(np.unique(ch))       # every hit channel fired (weight 1)
