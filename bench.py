@@ -27,6 +27,7 @@ CONFIGS = {
     'detector': ('detector', 10_000_000, 'demo.detector() (10 055 PMTs, 59 M triangles), 1e7-photon 400 nm bomb'),
     'lite': ('detector_lite', 10_000_000, 'C2-lite (501 PMTs, ~3 M triangles), 1e7-photon 400 nm bomb'),
     'tiny': ('tiny', 1_000_000, 'demo.tiny() (53 PMTs, 390 k triangles), 1e6-photon 400 nm bomb'),
+    'c5': ('scintillator_stress', 10_000_000, 'scintillator cube with thin-film / WLS / dichroic / detecting faces, 1e7-photon 350 nm bomb'),
 }
 ENGINE_SEED = 12345
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -95,7 +96,7 @@ def main():
 
     lib = ctx._lib
     nbatches = args.warmup + args.steps
-    wl_lo, wl_hi = 400.0, args.wavelength_hi
+    wl_lo, wl_hi = (350.0 if args.config == 'c5' else 400.0), args.wavelength_hi
 
     class Batch(object):
         """Device photon arrays filled by the on-device bomb generator."""

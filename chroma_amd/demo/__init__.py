@@ -63,3 +63,9 @@ def detector_lite():
 def detector29k():
     """29 007 PMTs at the demo pitch."""
     return detector(pmt_radius=23780.0, sphere_radius=24280.0, spiral_step=350.0)
+
+
+def scintillator_stress():
+    """Scintillator + thin film + WLS + dichroic + detecting surface."""
+    from chroma_amd.demo.stress import scintillator_stress as build
+    return build()
