@@ -95,7 +95,13 @@ class GPUPhotons(object):
 
     # ---- propagation ---------------------------------------------------------------------------
     def _rng(self, rng_states):
-        """chroma_rng for this photon set: the id block is reserved on first use."""
+        """chroma_rng for this photon set: the id block is reserved on first use.  A slice made by
+        iterate_copies() uses its parent's block, shifted by its offset, so a photon keeps its stream."""
+        parent = getattr(self, '_rng_parent', None)
+        if parent is not None:
+            base = parent[0]._rng(rng_states)
+            if isinstance(rng_states, RNGStates):
+                return _lib.Rng(base.seed, base.photon_id_base + parent[1])
         if isinstance(rng_states, RNGStates):
             if self._rng_base is None or getattr(self, '_rng_owner', None) is not rng_states:
                 self._rng_base = rng_states.reserve(len(self))
@@ -237,11 +243,13 @@ class GPUPhotons(object):
         """GPUPhotonsSlice views of the ``ncopies`` replicas."""
         for i in range(self.ncopies):
             w = slice(self.true_nphotons * i, self.true_nphotons * (i + 1))
-            yield GPUPhotonsSlice(pos=self.pos[w], dir=self.dir[w], pol=self.pol[w],
-                                  wavelengths=self.wavelengths[w], t=self.t[w],
-                                  last_hit_triangles=self.last_hit_triangles[w], flags=self.flags[w],
-                                  weights=self.weights[w], evidx=self.evidx[w],
-                                  rng_counters=self.rng_counters[w])
+            view = GPUPhotonsSlice(pos=self.pos[w], dir=self.dir[w], pol=self.pol[w],
+                                   wavelengths=self.wavelengths[w], t=self.t[w],
+                                   last_hit_triangles=self.last_hit_triangles[w], flags=self.flags[w],
+                                   weights=self.weights[w], evidx=self.evidx[w],
+                                   rng_counters=self.rng_counters[w])
+            view._rng_parent = (self, self.true_nphotons * i)
+            yield view
 
 
 class GPUPhotonsSlice(GPUPhotons):

@@ -342,3 +342,49 @@ def test_chroma_sim_driver(gpu, tmp_path):
         ch = f['ev%d/channel' % i]
         assert len(ch) > 50 and ch.max() < 53 and len(f['ev%d/t' % i]) == len(ch)
         assert f['ev%d/daq_hit' % i].sum() == len(np.unique(ch))       # every hit channel fired (weight 1)
+
+
+def test_c_abi_rejects_bad_input(gpu, tiny_geometry):
+    """Error behaviour at the boundary: a non-zero status + message instead of a crash."""
+    import ctypes
+    from chroma_amd import _lib
+    from chroma_amd.gpu.geometry import pack_geometry
+    ctx = gpu.get_context()
+    lib = ctx._lib
+    # geometry whose BVH points outside the node array
+    pk = pack_geometry(make_box_geometry(50.0))
+    nodes = pk.arrays['nodes']
+    saved = nodes[0, 3]
+    nodes[0, 3] = (3 << 28) | 5000
+    handle = ctypes.c_void_p()
+    rc = lib.chroma_geometry_create(ctx.handle, ctypes.byref(pk.desc), ctypes.byref(handle))
+    assert rc != 0 and b'child range' in lib.chroma_last_error()
+    nodes[0, 3] = saved
+    # triangle index out of range
+    tri = pk.arrays['triangles']
+    saved = tri[0, 0]
+    tri[0, 0] = 10 ** 6
+    rc = lib.chroma_geometry_create(ctx.handle, ctypes.byref(pk.desc), ctypes.byref(handle))
+    assert rc != 0 and b'vertex' in lib.chroma_last_error()
+    tri[0, 0] = saved
+    # null photon arrays
+    gg = gpu.GPUDetector(tiny_geometry)
+    empty = _lib.PhotonArrays()
+    rc = lib.chroma_propagate(ctx.handle, gg.handle, ctypes.byref(empty), 10, 1, _lib.Rng(1, 0), 5, 0, 0, 0, None, None)
+    assert rc != 0 and b'null' in lib.chroma_last_error()
+    with pytest.raises(_lib.ChromaError):
+        _lib.check(rc)
+    # hits on a geometry without a channel map
+    plain = gpu.GPUGeometry(make_box_geometry(50.0))
+    gp = gpu.GPUPhotons(bomb(10, 1))
+    with pytest.raises(_lib.ChromaError, match='channel map'):
+        gp.get_flat_hits(plain)
+    # copies keep their stream when propagated through a slice view
+    small = bomb(300, 5)
+    rng_a, rng_b = gpu.get_rng_states(1, seed=3), gpu.get_rng_states(1, seed=3)
+    a = gpu.GPUPhotons(small, ncopies=2)
+    a.propagate(gg, rng_a, max_steps=20)
+    b = gpu.GPUPhotons(small, ncopies=2)
+    for view in b.iterate_copies():
+        view.propagate(gg, rng_b, max_steps=20)
+    assert np.array_equal(a.get().flags, b.get().flags) and np.array_equal(a.get().t, b.get().t)
