@@ -129,9 +129,14 @@ SIGNATURES = {
     'chroma_bvh_fetch': (c_int32, [c_void_p, c_void_p, c_void_p]),
     'chroma_bvh_data': (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p)]),
     'chroma_bvh_free': (c_int32, [c_void_p]),
+    'chroma_wide_build': (c_int32, [c_void_p, c_uint64, c_uint32, POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64),
+                                    POINTER(c_uint32)]),
+    'chroma_wide_data': (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    'chroma_wide_free': (c_int32, [c_void_p]),
     'chroma_dedupe_vertices': (c_int32, [c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, POINTER(c_uint64)]),
     'chroma_propagate_stats_read': (c_int32, [c_void_p, POINTER(PropagateStats)]),
     'chroma_set_counting': (c_int32, [c_void_p, c_int32]),
+    'chroma_set_walk': (c_int32, [c_void_p, c_int32]),
 }
 
 _lib = None
@@ -197,6 +202,33 @@ def bvh_build(vertices, triangles, world_origin, world_scale, target_degree=3):
     import weakref
     weakref.finalize(raw, lib.chroma_bvh_free, handle)
     return nodes, bounds.astype(np.int64)
+
+
+def wide_build(nodes, ntriangles):
+    """The derived 8-wide traversal tree of a reference-format BVH (host side; what
+    chroma_geometry_create uploads).  Returns a dict of copies: ``wnodes`` [nwide][8][4] uint32,
+    ``tri_to_record``, ``record_to_tri``, ``rank`` and ``depth``."""
+    lib = load()
+    raw = np.ascontiguousarray(nodes).view(np.uint32).reshape(-1, 4)
+    handle = c_void_p()
+    nwide, nrec, depth = c_uint64(), c_uint64(), c_uint32()
+    rc = lib.chroma_wide_build(ptr(raw), len(raw), int(ntriangles), ctypes.byref(handle), ctypes.byref(nwide),
+                               ctypes.byref(nrec), ctypes.byref(depth))
+    if rc != 0:
+        raise ChromaError('chroma_wide_build failed (%d): malformed BVH' % rc)
+    try:
+        p = [c_void_p() for _ in range(4)]
+        check(lib.chroma_wide_data(handle, *[ctypes.byref(x) for x in p]))
+
+        def copy(pp, n):
+            if n == 0:
+                return np.zeros(0, dtype=np.uint32)
+            return np.array((ctypes.c_uint32 * n).from_address(pp.value), dtype=np.uint32)
+        return {'wnodes': copy(p[0], 32 * nwide.value).reshape(-1, 8, 4),
+                'tri_to_record': copy(p[1], int(ntriangles)), 'record_to_tri': copy(p[2], nrec.value),
+                'rank': copy(p[3], int(ntriangles)), 'depth': depth.value}
+    finally:
+        lib.chroma_wide_free(handle)
 
 
 def dedupe_vertices(vertices, triangles):

@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "propagate_device.h"
+#include "wide_build.h"
 
 // ---------------------------------------------------------------------------------------------------
 // error handling
@@ -53,6 +54,9 @@ struct chroma_ctx {
     uint32_t *h_words = nullptr;        // pinned mirror
     int counting = 0;
     int persistent_waves = 256 * 20 * 4;   // grid of the persistent ray-cast kernel (set from the device at init)
+    int wide_waves = 256 * 14;             // same for k_raycast_wide (11 KB of LDS per wave)
+    uint2 *wide_spill = nullptr;           // [wide_waves][WIDE_SPILL][64] stack entries beyond the LDS part
+    int wide_walk = 1;                     // 0 (CHROMA_WALK=reference): ray cast over the reference tree only
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
 };
 
@@ -62,8 +66,8 @@ struct chroma_geometry {
     std::vector<void *> allocations;
     void *d_vertices = nullptr, *d_triangles = nullptr, *d_material_codes = nullptr, *d_colors = nullptr;
     void *d_nodes_api = nullptr;       // nodes exactly as passed in (GPUGeometry.nodes)
-    size_t nvertices = 0, ntriangles = 0, nnodes = 0;
-    uint32_t stack_need = 0;
+    size_t nvertices = 0, ntriangles = 0, nnodes = 0, nwide = 0, nrecords = 0;
+    uint32_t stack_need = 0, wide_depth = 0, wide_stack_need = 0;
     size_t device_bytes = 0;
 };
 
@@ -380,6 +384,211 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, int nthreads, c
                     if (triangle_index == -1 || distance < min_distance) {
                         triangle_index = (int)tri;
                         min_distance = distance;
+                    }
+                }
+            }
+        }
+        npend = 0;
+
+        // ---- retire finished rays
+        if (has_ray && !active) {
+            hit_triangle[slot] = (triangle_index >= 0) ? (int)g.dev_to_tri[triangle_index] : triangle_index;
+            hit_distance[slot] = min_distance;
+            if (triangle_index == HIT_RETRY) atomicAdd(retry_counter, 1u);
+            has_ray = false;
+        }
+    }
+
+    if (COUNT) {
+        unsigned long long st = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        if (lane == 0) {
+            atomicAdd(&counters->photon_steps, st);
+            atomicAdd(&counters->nodes_visited, nd);
+            atomicAdd(&counters->triangles_tested, tr);
+        }
+    }
+}
+
+// ---- persistent ray cast over the derived 8-wide tree ---------------------------------------------
+// Same frame as k_raycast_persistent (one ray per lane, lanes refilled from the queue), but a node
+// visit is one 128-byte line: eight child boxes tested with the fast slab test, triangle children
+// noted for the leaf phase, the nearest inner child walked next and the others pushed with their
+// box distance so that a popped entry farther than the best hit costs nothing.  The visiting order
+// is NOT the reference's; the result is, because the walk is conservative and exact ties between
+// triangles are broken by the reference's test order (`rank`, see csrc/wide_build.cpp).
+// Rays this kernel cannot take (1/d not moderate, more than WIDE_STACK entries) go to
+// k_raycast_retry as before.
+#ifndef WIDE_STACK
+#define WIDE_STACK 16        // (node, distance) entries per lane in LDS
+#endif
+#ifndef WIDE_PENDING
+#define WIDE_PENDING 12      // postponed triangle tests per lane in LDS
+#endif
+#ifndef WIDE_FLUSH
+#define WIDE_FLUSH 5         // run the leaf phase once a lane holds this many (a visit adds up to 8)
+#endif
+#ifndef WIDE_SPILL
+#define WIDE_SPILL 112       // further entries per lane in global memory (rarely touched)
+#endif
+#define WIDE_NONE 0xFFFFFFFFu
+
+template <bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
+k_raycast_wide(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
+               int32_t *hit_triangle, float *hit_distance, uint32_t *work_counter, uint32_t *retry_counter,
+               uint2 *spill_base, DeviceCounters *counters)
+{
+    static_assert(WIDE_FLUSH - 1 + 8 <= WIDE_PENDING, "a node visit must fit the FIFO");
+    static_assert(PROP_BLOCK == WAVE, "one wave per workgroup: blockIdx.x names the wave's spill area");
+    // stack entries beyond the LDS part live in this wave's slice of a global buffer, [entry][lane]
+    uint2 *spill = spill_base + (size_t)blockIdx.x * WIDE_SPILL * PROP_BLOCK + threadIdx.x;
+    __shared__ uint32_t s_lds[(2 * WIDE_STACK + WIDE_PENDING) * PROP_BLOCK];
+    uint32_t *stack_n = s_lds + threadIdx.x;
+    float *stack_t = (float *)(stack_n + WIDE_STACK * PROP_BLOCK);
+    uint32_t *pending = stack_n + 2 * WIDE_STACK * PROP_BLOCK;
+    const unsigned lane = lane_id();
+    LaneCounters cnt = {0, 0, 0, 0};
+
+    bool has_ray = false, active = false;
+    int slot = 0;
+    v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
+    RayFast rf;
+    rf.a = rf.blo = rf.bhi = mk3(0.f, 0.f, 0.f);
+    int last_hit = -1, triangle_index = -1;
+    uint32_t best_rank = 0;
+    float min_distance = -1.0f;
+    uint32_t cur = WIDE_NONE;
+    int sp = 0, npend = 0;
+    bool exhausted = false;
+
+    for (;;) {
+        // ---- refill idle lanes
+        unsigned long long idle_mask = __ballot(!has_ray);
+        int n_idle = __popcll(idle_mask);
+        if (!exhausted && (n_idle >= RAY_REFILL_MIN || n_idle == WAVE)) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(work_counter, (uint32_t)n_idle);
+            base = __shfl(base, 0);
+            if (base + (uint32_t)n_idle >= (uint32_t)nthreads) exhausted = true;
+            if (!has_ray) {
+                uint32_t idx = base + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (idx < (uint32_t)nthreads) {
+                    slot = first_photon + (int)idx;
+                    uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
+                    int result = HIT_SKIP;
+                    if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
+                        origin = load3(pv.pos, photon_id);
+                        direction = load3(pv.dir, photon_id);
+                        direction = direction / norm(direction);
+                        if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
+                            result = HIT_NAN;
+                        } else {
+                            v3 noid = (-origin) / direction;
+                            v3 inv_dir = 1.0f / direction;
+                            bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                                            cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+                            if (!moderate) {
+                                result = HIT_RETRY;
+                            } else {
+                                if (COUNT) cnt.steps++;
+                                rf = ray_fast(g, noid, inv_dir);
+                                last_hit = pv.last_hit_triangles[photon_id];
+                                if (last_hit >= 0) last_hit = (int)g.tri_to_dev[last_hit];
+                                triangle_index = -1;
+                                min_distance = -1.0f;
+                                sp = 0;
+                                npend = 0;
+                                cur = 0;                 // the wide root holds the children of the reference root
+                                has_ray = true;
+                                active = true;
+                                result = 0;
+                            }
+                        }
+                    }
+                    if (!has_ray) {
+                        hit_triangle[slot] = result;
+                        hit_distance[slot] = 0.0f;
+                        if (result == HIT_RETRY) atomicAdd(retry_counter, 1u);
+                    }
+                }
+            }
+        }
+        if (!__any(has_ray)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- node phase: one wide node per active lane per iteration
+        const int stop_at = exhausted ? 0 : max(0, __popcll(__ballot(active)) - RAY_REFILL_MIN);
+        do {
+            if (active && cur == WIDE_NONE) {
+                // next entry that can still hold a nearer hit
+                while (sp > 0) {
+                    sp--;
+                    uint32_t n; float t;
+                    if (sp < WIDE_STACK) { n = stack_n[sp * PROP_BLOCK]; t = stack_t[sp * PROP_BLOCK]; }
+                    else { uint2 e = spill[(size_t)(sp - WIDE_STACK) * PROP_BLOCK]; n = e.x; t = __uint_as_float(e.y); }
+                    if (min_distance < 0.0f || !(t > min_distance)) { cur = n; break; }
+                }
+                if (cur == WIDE_NONE) active = false;
+            }
+            if (active) {
+                const uint4 *wn = g.wnodes + 8 * (size_t)cur;
+                uint4 c[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) c[j] = wn[j];
+                if (COUNT) cnt.nodes += 8;
+                uint32_t nxt = WIDE_NONE;
+                float nxt_t = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float t = box_tmin_fast(rf, c[j]);
+                    uint32_t w = c[j].w;
+                    if (w != WIDE_NONE && node_passes(t, min_distance)) {
+                        if (w & 0x80000000u) {
+                            uint32_t tri = w & 0x7FFFFFFFu;
+                            if ((int)tri != last_hit) {
+                                pending[npend * PROP_BLOCK] = tri;
+                                npend++;
+                            }
+                        } else if (nxt == WIDE_NONE) {
+                            nxt = w; nxt_t = t;
+                        } else {
+                            uint32_t pw = w; float pt = t;
+                            if (t < nxt_t) { pw = nxt; pt = nxt_t; nxt = w; nxt_t = t; }
+                            if (sp < WIDE_STACK) {
+                                stack_n[sp * PROP_BLOCK] = pw;
+                                stack_t[sp * PROP_BLOCK] = pt;
+                                sp++;
+                            } else if (sp < WIDE_STACK + WIDE_SPILL) {
+                                spill[(size_t)(sp - WIDE_STACK) * PROP_BLOCK] = make_uint2(pw, __float_as_uint(pt));
+                                sp++;
+                            } else {                                 // cannot happen: the host checked the tree's need
+                                if (COUNT && triangle_index != HIT_RETRY) cnt.steps--;   // counted again by the retry pass
+                                triangle_index = HIT_RETRY;
+                            }
+                        }
+                    }
+                }
+                cur = nxt;
+                if (triangle_index == HIT_RETRY) { active = false; npend = 0; cur = WIDE_NONE; sp = 0; }
+            }
+        } while (!__any(npend >= WIDE_FLUSH) && __popcll(__ballot(active)) > stop_at);
+
+        // ---- leaf phase: postponed triangle tests
+        for (int j = 0; __any(j < npend); j++) {
+            if (j < npend) {
+                uint32_t tri = pending[j * PROP_BLOCK];
+                if (COUNT) cnt.tris++;
+                const float4 *t = g.tri + 3 * (size_t)tri;
+                float4 a = t[0], b = t[1], cc = t[2];
+                float distance;
+                if (intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), distance)) {
+                    uint32_t rank = __float_as_uint(cc.w);
+                    if (triangle_index == -1 || distance < min_distance || (distance == min_distance && rank < best_rank)) {
+                        triangle_index = (int)tri;
+                        min_distance = distance;
+                        best_rank = rank;
                     }
                 }
             }
@@ -832,9 +1041,29 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     // persistent ray cast: enough waves to fill the chip a few times over, each pulling rays
     // from the queue through ctx->d_words[4]; d_words[5] counts the rays left for the retry pass
     HIP_TRY(hipMemsetAsync(ctx->d_words + 4, 0, 8, ctx->stream));
-    unsigned waves = (unsigned)std::min<long long>(((long long)nthreads + PROP_BLOCK - 1) / PROP_BLOCK, (long long)ctx->persistent_waves);
+    const bool wide = ctx->wide_walk && geom->view.wnodes && geom->wide_stack_need <= WIDE_STACK + WIDE_SPILL;
+    if (wide && !ctx->wide_spill) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMalloc((void **)&ctx->wide_spill, (size_t)ctx->wide_waves * WIDE_SPILL * PROP_BLOCK * sizeof(uint2)));
+    }
+    unsigned waves = (unsigned)std::min<long long>(((long long)nthreads + PROP_BLOCK - 1) / PROP_BLOCK,
+                                                   (long long)(wide ? ctx->wide_waves : ctx->persistent_waves));
     dim3 grid(waves), block(PROP_BLOCK);
-    if (ctx->counting) {
+    if (wide) {
+        if (ctx->counting)
+            hipLaunchKernelGGL((k_raycast_wide<true>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
+                               ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 4, ctx->d_words + 5, ctx->wide_spill, ctx->d_counters);
+        else
+            hipLaunchKernelGGL((k_raycast_wide<false>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
+                               ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 4, ctx->d_words + 5, ctx->wide_spill, ctx->d_counters);
+        if (mark_raycast_end) HIP_TRY(hipEventRecord(ctx->ev_mid, ctx->stream));
+        if (ctx->counting)
+            hipLaunchKernelGGL((k_raycast_retry<true>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
+                               ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
+        else
+            hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
+                               ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
+    } else if (ctx->counting) {
         hipLaunchKernelGGL((k_raycast_persistent<true>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
                            ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 4, ctx->d_words + 5, ctx->d_counters);
         if (mark_raycast_end) HIP_TRY(hipEventRecord(ctx->ev_mid, ctx->stream));
@@ -935,6 +1164,10 @@ int chroma_init(int device, chroma_ctx **out)
         int per_cu = 20;                     // LDS-limited residency of k_raycast_persistent (8 KB per wave)
         if (const char *e = getenv("CHROMA_RAY_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));
         ctx->persistent_waves = prop.multiProcessorCount * per_cu;
+        int wide_per_cu = 14;                // LDS-limited residency of k_raycast_wide
+        if (const char *e = getenv("CHROMA_WIDE_WAVES_PER_CU")) wide_per_cu = std::max(1, atoi(e));
+        ctx->wide_waves = prop.multiProcessorCount * wide_per_cu;
+        if (const char *e = getenv("CHROMA_WALK")) ctx->wide_walk = (strcmp(e, "reference") != 0);
     }
     HIP_TRY(hipEventCreate(&ctx->ev_start));
     HIP_TRY(hipEventCreate(&ctx->ev_stop));
@@ -950,6 +1183,7 @@ int chroma_shutdown(chroma_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     if (ctx->queue_a) hipFree(ctx->queue_a);
     if (ctx->queue_b) hipFree(ctx->queue_b);
+    if (ctx->wide_spill) hipFree(ctx->wide_spill);
     if (ctx->hit_triangle) hipFree(ctx->hit_triangle);
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
     hipFree(ctx->d_counters);
@@ -1088,24 +1322,21 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
 #define UP(field, src, count) if ((rc = upload(g, src, (size_t)(count), &v.field)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; }
     // nodes as passed in (what GPUGeometry.nodes shows)
     { const uint4 *p; if ((rc = upload(g, (const uint4 *)d->nodes, d->nnodes, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_nodes_api = (void *)p; }
-    // device triangle order = order of the leaf layer (the trailing run of leaf nodes), so that
-    // the triangles of sibling leaves share cache lines
-    std::vector<uint32_t> tri_to_dev(d->ntriangles, 0xFFFFFFFFu), dev_to_tri;
-    dev_to_tri.reserve(d->ntriangles);
+    // derived 8-wide tree, device triangle order and reference test ranks (csrc/wide_build.cpp)
+    chroma_host::WideTree wt;
     {
-        size_t start = d->nnodes;
-        while (start > 0 && (d->nodes[4 * (start - 1) + 3] >> CHROMA_CHILD_BITS) == 0) start--;
-        auto take = [&](size_t i) {
-            uint32_t w = d->nodes[4 * i + 3];
-            if ((w >> CHROMA_CHILD_BITS) != 0) return;
-            uint32_t t = w & ~CHROMA_NCHILD_MASK;
-            if (tri_to_dev[t] == 0xFFFFFFFFu) { tri_to_dev[t] = (uint32_t)dev_to_tri.size(); dev_to_tri.push_back(t); }
-        };
-        for (size_t i = start; i < d->nnodes; i++) take(i);
-        for (size_t i = 0; i < start; i++) take(i);
-        for (uint32_t t = 0; t < d->ntriangles; t++)
-            if (tri_to_dev[t] == 0xFFFFFFFFu) { tri_to_dev[t] = (uint32_t)dev_to_tri.size(); dev_to_tri.push_back(t); }
+        std::string werr;
+        if (chroma_host::build_wide_tree(d->nodes, d->nnodes, d->ntriangles, wt, werr) != 0) {
+            chroma_geometry_destroy(g);
+            return set_error(CHROMA_ERR_INVALID, "%s", werr.c_str());
+        }
     }
+    const std::vector<uint32_t> &tri_to_dev = wt.tri_to_dev, &dev_to_tri = wt.dev_to_tri;
+    const size_t nrecords = dev_to_tri.size();
+    { const uint4 *p; if ((rc = upload(g, (const uint4 *)wt.wnodes.data(), wt.nwide * 8, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } v.wnodes = p; }
+    v.nwide = (uint32_t)wt.nwide;
+    g->nwide = wt.nwide; g->wide_depth = wt.depth; g->nrecords = nrecords; g->wide_stack_need = wt.stack_need;
+    { std::vector<uint32_t>().swap(wt.wnodes); }
     UP(tri_to_dev, tri_to_dev.data(), tri_to_dev.size());
     UP(dev_to_tri, dev_to_tri.data(), dev_to_tri.size());
     // traversal copy of the nodes: leaf child -> device triangle index
@@ -1133,15 +1364,15 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     // 48-byte triangle records in device order, staged in chunks
     {
         void *dtri = nullptr;
-        size_t bytes = (size_t)d->ntriangles * 48;
+        size_t bytes = nrecords * 48;
         hipError_t e = hipMalloc(&dtri, bytes);
         if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "hipMalloc(%zu) for triangle records: %s", bytes, hipGetErrorString(e)); }
         g->allocations.push_back(dtri);
         g->device_bytes += bytes;
         const size_t CH = 1u << 22;
-        std::vector<float> stage(std::min((size_t)d->ntriangles, CH) * 12);
-        for (size_t t0 = 0; t0 < d->ntriangles; t0 += CH) {
-            size_t t1 = std::min((size_t)d->ntriangles, t0 + CH);
+        std::vector<float> stage(std::min(nrecords, CH) * 12);
+        for (size_t t0 = 0; t0 < nrecords; t0 += CH) {
+            size_t t1 = std::min(nrecords, t0 + CH);
             for (size_t k = t0; k < t1; k++) {
                 size_t t = dev_to_tri[k];
                 float *r = stage.data() + (k - t0) * 12;
@@ -1149,8 +1380,8 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
                     const float *vv = d->vertices + 3 * (size_t)d->triangles[3 * t + c];
                     r[4 * c] = vv[0]; r[4 * c + 1] = vv[1]; r[4 * c + 2] = vv[2];
                 }
-                uint32_t code = d->material_codes[t], sid = d->solid_id_map ? d->solid_id_map[t] : 0u, zero = 0u;
-                memcpy(&r[3], &code, 4); memcpy(&r[7], &sid, 4); memcpy(&r[11], &zero, 4);
+                uint32_t code = d->material_codes[t], sid = d->solid_id_map ? d->solid_id_map[t] : 0u, rank = wt.rank[t];
+                memcpy(&r[3], &code, 4); memcpy(&r[7], &sid, 4); memcpy(&r[11], &rank, 4);
             }
             e = hipMemcpy((char *)dtri + t0 * 48, stage.data(), (t1 - t0) * 48, hipMemcpyHostToDevice);
             if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "triangle upload: %s", hipGetErrorString(e)); }
@@ -1233,7 +1464,10 @@ int chroma_geometry_device_ptr(chroma_geometry *g, const char *name, void **d_pt
     else if (n == "colors") { p = g->d_colors; bytes = g->ntriangles * 4; }
     else if (n == "solid_id_map") { p = (void *)g->view.solid_id_map; bytes = g->ntriangles * 4; }
     else if (n == "solid_id_to_channel_index") { p = (void *)g->view.solid_id_to_channel_index; bytes = (size_t)g->view.nsolids * 4; }
-    else if (n == "triangle_records") { p = (void *)g->view.tri; bytes = g->ntriangles * 48; }
+    else if (n == "triangle_records") { p = (void *)g->view.tri; bytes = g->nrecords * 48; }
+    else if (n == "wide_nodes") { p = (void *)g->view.wnodes; bytes = g->nwide * 128; }
+    else if (n == "tri_to_dev") { p = (void *)g->view.tri_to_dev; bytes = g->ntriangles * 4; }
+    else if (n == "dev_to_tri") { p = (void *)g->view.dev_to_tri; bytes = g->nrecords * 4; }
     else return set_error(CHROMA_ERR_INVALID, "unknown geometry array '%s'", name);
     *d_ptr = p;
     if (nbytes) *nbytes = bytes;
@@ -1416,6 +1650,14 @@ int chroma_set_counting(chroma_ctx *ctx, int32_t enabled)
 {
     if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
     ctx->counting = enabled ? 1 : 0;
+    return CHROMA_OK;
+}
+
+int chroma_set_walk(chroma_ctx *ctx, int32_t mode)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    if (mode != CHROMA_WALK_REFERENCE && mode != CHROMA_WALK_WIDE) return set_error(CHROMA_ERR_INVALID, "unknown walk mode %d", mode);
+    ctx->wide_walk = (mode == CHROMA_WALK_WIDE);
     return CHROMA_OK;
 }
 

@@ -37,19 +37,24 @@ __device__ inline void store3(float *p, size_t i, v3 v) { p[3 * i] = v.x; p[3 * 
 // ---- device view of an uploaded geometry ------------------------------------------------
 // Layout in HBM (see DESIGN.md "Data layout"):
 //   nodes   uint4[nnodes]            16 B packed node, as chroma/cuda/geometry_types.h:57-67
-//   tri     float4[ntriangles][3]    48 B record: v0.xyz|material_code, v1.xyz|solid_id, v2.xyz|0
+//   wnodes  uint4[nwide][8]          128 B wide node = one L2 line: eight child entries in the node
+//                                    format above, w = child wide node | 0x80000000+device triangle
+//                                    | 0xFFFFFFFF (empty); derived from `nodes` (csrc/wide_build.cpp)
+//   tri     float4[nrecords][3]      48 B record: v0.xyz|material_code, v1.xyz|solid_id, v2.xyz|rank
 //                                    (one aligned 48-B gather instead of the reference's
-//                                     12-B index fetch + three 12-B vertex gathers).  Records are
-//                                    stored in LEAF order (the Morton order of the BVH's leaf layer),
-//                                    not in triangle-id order: the leaves under one parent -- tested
-//                                    together -- then sit in the same or adjacent 128-B lines.  The
-//                                    traversal's copy of the nodes holds that "device" index in its
-//                                    leaves; tri_to_dev / dev_to_tri translate at ray start and end.
+//                                     12-B index fetch + three 12-B vertex gathers).  `rank` is the
+//                                    triangle's position in the reference's test order (tie-break of
+//                                    the wide walk).  Records are stored in the order the wide tree
+//                                    lists its triangles, not in triangle-id order: the triangles of
+//                                    one wide node -- tested together -- sit in adjacent 128-B lines.
+//                                    Both trees hold that "device" index in their leaves;
+//                                    tri_to_dev / dev_to_tri translate at ray start and end.
 //   tables  float[...]               optics tables, row-major [row][wavelength_n]
 struct SurfaceInfo { uint32_t model; uint32_t transmissive; float thickness; int32_t dichroic_index; };
 
 struct GeoView {
     const uint4  *nodes;             // traversal copy: leaf child = device triangle index
+    const uint4  *wnodes;            // derived 8-wide tree, 8 entries (128 B) per node
     const float4 *tri;               // [device triangle index][3]
     const uint32_t *tri_to_dev, *dev_to_tri;
     // materials
@@ -69,7 +74,7 @@ struct GeoView {
     float world_scale;
     uint32_t wavelength_n; float wavelength_start, wavelength_step;
     uint32_t time_n;       float time_start, time_step;
-    uint32_t nnodes, ntriangles, nsolids, nchannels;
+    uint32_t nnodes, ntriangles, nsolids, nchannels, nwide;
 };
 
 struct PhotonView {   // device pointers of chroma_photon_arrays

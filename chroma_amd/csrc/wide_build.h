@@ -1,0 +1,26 @@
+// wide_build.h -- the derived 8-wide traversal tree (see wide_build.cpp).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+
+namespace chroma_host {
+
+enum : uint32_t { WIDE_K = 8, WIDE_LEAF = 0x80000000u, WIDE_EMPTY = 0xFFFFFFFFu };
+
+struct WideTree {
+    std::vector<uint32_t> wnodes;       // nwide * 8 entries of 4 words: x, y, z boxes, w = child (see above)
+    std::vector<uint32_t> tri_to_dev;   // [ntriangles] device record index of a triangle
+    std::vector<uint32_t> dev_to_tri;   // [nrecords >= ntriangles] triangle of a device record
+    std::vector<uint32_t> rank;         // [ntriangles] position in the reference's test order (0xFFFFFFFF: under no leaf)
+    size_t nwide = 0;
+    uint32_t depth = 0;                 // levels of wide nodes
+    uint32_t stack_need = 0;            // most entries the nearest-first walk can hold at once
+};
+
+// nodes: reference-format BVH (4 words per node, root first, children of a node contiguous and
+// stored after every node of their parent's layer).  Returns 0, or -1 with `err` set.
+int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, WideTree &out, std::string &err);
+
+}  // namespace chroma_host

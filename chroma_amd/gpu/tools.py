@@ -85,6 +85,10 @@ class Context(object):
     def set_counting(self, enabled):
         _lib.check(self._lib.chroma_set_counting(self.handle, 1 if enabled else 0))
 
+    def set_walk(self, mode):
+        """'wide' (default) or 'reference': the tree the per-step ray cast walks (same results)."""
+        _lib.check(self._lib.chroma_set_walk(self.handle, {'reference': 0, 'wide': 1}[mode]))
+
     def read_stats(self):
         stats = _lib.PropagateStats()
         _lib.check(self._lib.chroma_propagate_stats_read(self.handle, ctypes.byref(stats)))

@@ -297,6 +297,23 @@ int chroma_bvh_fetch(void *handle, uint32_t *nodes_out, uint64_t *layer_bounds_o
 int chroma_bvh_data(void *handle, const uint32_t **nodes, const uint64_t **layer_bounds);
 int chroma_bvh_free(void *handle);
 
+/* ---- derived traversal tree ------------------------------------------------------------
+ * chroma_geometry_create derives, from the reference-format nodes it is given, the tree the ray
+ * cast actually walks on MI355X: 8-wide nodes of 128 bytes (one L2 line) whose entries are boxes
+ * of the reference tree (chroma/cuda/geometry_types.h:57-67 format, w = child wide node, or
+ * 0x80000000 | record index of a triangle, or 0xFFFFFFFF for an empty slot), the order of the
+ * 48-byte triangle records, and each triangle's position in the test order of the reference
+ * walk (chroma/cuda/mesh.h:68-110), which breaks exact distance ties the way the reference does.
+ * These entry points expose that host-side step on its own (no device needed) for inspection
+ * and tests; arrays stay owned by the handle until chroma_wide_free.
+ *   wnodes      [nwide][8][4] uint32      tri_to_record [ntriangles] uint32
+ *   record_to_tri [nrecords] uint32       rank [ntriangles] uint32 (0xFFFFFFFF: under no leaf) */
+int chroma_wide_build(const uint32_t *nodes, uint64_t nnodes, uint32_t ntriangles, void **handle,
+                      uint64_t *nwide, uint64_t *nrecords, uint32_t *depth);
+int chroma_wide_data(void *handle, const uint32_t **wnodes, const uint32_t **tri_to_record,
+                     const uint32_t **record_to_tri, const uint32_t **rank);
+int chroma_wide_free(void *handle);
+
 /* Merge identical vertices of a flattened mesh: replaces Mesh.remove_duplicate_vertices
  * (chroma/geometry.py:58-67, np.unique on a structured view) for large meshes.  The survivors
  * are written to `unique_out` ([nvertices][3] capacity) in lexicographic (x, y, z) order and
@@ -308,6 +325,14 @@ int chroma_dedupe_vertices(const float *vertices, uint64_t nvertices, uint32_t *
 int chroma_propagate_stats_read(chroma_ctx *ctx, chroma_propagate_stats *stats);
 /* enable (1) / disable (0) node/triangle visit counting in the propagate kernels */
 int chroma_set_counting(chroma_ctx *ctx, int32_t enabled);
+
+/* Which tree the one-step ray cast walks: the derived 8-wide tree (default) or the
+ * reference-format nodes in the reference's own order.  Results are identical by construction;
+ * the switch exists so that tests and benchmarks can show it.  Env CHROMA_WALK=reference sets
+ * the initial mode of a context. */
+#define CHROMA_WALK_REFERENCE 0
+#define CHROMA_WALK_WIDE      1
+int chroma_set_walk(chroma_ctx *ctx, int32_t mode);
 
 #ifdef __cplusplus
 }

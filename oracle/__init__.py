@@ -122,6 +122,21 @@ def distance_to_mesh(packed, origins, directions, variant='contract'):
     return dist, tri, stats.as_dict()
 
 
+def reference_test_order(nodes, variant='contract'):
+    """Triangles in the order the reference walk tests them when every box is entered (see
+    oracle_reference_test_order).  ``nodes``: packed uint4 record array or [n][4] uint32."""
+    lib = load(variant)
+    raw = np.ascontiguousarray(nodes).view(np.uint32).reshape(-1, 4)
+    nleaf = int(((raw[:, 3] >> 28) == 0).sum())
+    out = np.empty(max(nleaf, 1), dtype=np.uint32)
+    lib.oracle_reference_test_order.restype = ctypes.c_int64
+    lib.oracle_reference_test_order.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    n = lib.oracle_reference_test_order(raw.ctypes.data, len(raw), out.ctypes.data, len(out))
+    if n < 0:
+        raise RuntimeError('reference stack overflow')
+    return out[:min(n, len(out))]
+
+
 def generate_bomb(n, seed, id_base=0, pos=(0, 0, 0), wavelength_lo=400.0, wavelength_hi=0.0, variant='contract'):
     lib = load(variant)
     hp = HostPhotons(n=n)

@@ -1039,6 +1039,41 @@ int oracle_distance_to_mesh(const chroma_geometry_desc *g, uint64_t n, const flo
     return 0;
 }
 
+/* Test order of the reference walk: the loop of intersect_mesh (mesh.h:58-110) with EVERY box test
+ * succeeding and no triangle hit (so nothing is pruned).  order_out[k] = k-th triangle tested;
+ * returns the number of tests, or -1 when the explicit stack (mesh.h: 1000 entries) would overflow.
+ * Pins the `rank` array the engine's wide walk uses to break exact distance ties. */
+int64_t oracle_reference_test_order(const uint32_t *nodes, uint64_t nnodes, uint32_t *order_out, uint64_t capacity)
+{
+    enum { STACK = 1000 };
+    uint32_t child_ptr_stack[STACK], nchild_ptr_stack[STACK];
+    int64_t ntests = 0;
+    if (nnodes == 0) return 0;
+    uint32_t root_w = nodes[3];
+    child_ptr_stack[0] = root_w & ~CHROMA_NCHILD_MASK;
+    nchild_ptr_stack[0] = root_w >> CHROMA_CHILD_BITS;
+    int curr = 0;
+    while (curr >= 0) {
+        uint32_t first_child = child_ptr_stack[curr];
+        uint32_t nchild = nchild_ptr_stack[curr];
+        curr--;
+        for (uint32_t i = first_child; i < first_child + nchild; i++) {
+            uint32_t w = nodes[4 * (uint64_t)i + 3];
+            uint32_t k = w >> CHROMA_CHILD_BITS, c = w & ~CHROMA_NCHILD_MASK;
+            if (k == 0) {
+                if ((uint64_t)ntests < capacity) order_out[ntests] = c;
+                ntests++;
+            } else {
+                curr++;
+                if (curr >= STACK) return -1;
+                child_ptr_stack[curr] = c;
+                nchild_ptr_stack[curr] = k;
+            }
+        }
+    }
+    return ntests;
+}
+
 /* ---- DAQ: run_daq (chroma/cuda/daq.cu:35-86) with interp (interpolate.h:32-57) -------------- */
 static float interp_table(float x, int n, const float *xp, const float *fp)
 {

@@ -1,0 +1,133 @@
+"""The derived 8-wide traversal tree (chroma_amd/csrc/wide_build.cpp): structure invariants and the
+reference test-order ranks, checked against the oracle's replay of the reference loop
+(chroma/cuda/mesh.h:58-110).  Host code only -- no GPU."""
+import numpy as np
+import pytest
+
+import oracle
+from chroma_amd import _lib, demo
+from chroma_amd.loader import create_geometry_from_obj
+from chroma_amd.geometry import Solid, Geometry, vacuum
+from chroma_amd import make
+
+LEAF = 0x80000000
+EMPTY = 0xFFFFFFFF
+
+
+def _geometries():
+    cube = Geometry()
+    cube.add_solid(Solid(make.cube(100.0), vacuum, vacuum))
+    yield 'cube', create_geometry_from_obj(cube)
+    yield 'tiny', create_geometry_from_obj(demo.tiny())
+
+
+@pytest.fixture(scope='module', params=['cube', 'tiny'])
+def built(request):
+    for name, g in _geometries():
+        if name == request.param:
+            nodes = np.ascontiguousarray(g.bvh.nodes)
+            return g, nodes.view(np.uint32).reshape(-1, 4), _lib.wide_build(nodes, len(g.mesh.triangles))
+
+
+def _lo_hi(words):
+    w = words[..., :3]
+    return (w & 0xFFFF).astype(np.int64), (w >> 16).astype(np.int64)
+
+
+def test_every_triangle_is_one_record(built):
+    g, ref, w = built
+    nt = len(g.mesh.triangles)
+    assert len(w['record_to_tri']) == nt
+    assert np.array_equal(np.sort(w['record_to_tri']), np.arange(nt))
+    assert np.array_equal(w['record_to_tri'][w['tri_to_record']], np.arange(nt))
+    ent = w['wnodes'].reshape(-1, 4)
+    leaf = ent[(ent[:, 3] & LEAF != 0) & (ent[:, 3] != EMPTY)]
+    assert np.array_equal(np.sort(leaf[:, 3] & 0x7FFFFFFF), np.arange(nt))      # each record under exactly one entry
+    # triangle children of a node are consecutive records
+    for node in w['wnodes'][:2000]:
+        recs = [int(e[3] & 0x7FFFFFFF) for e in node if e[3] != EMPTY and e[3] & LEAF]
+        assert recs == list(range(recs[0], recs[0] + len(recs))) if recs else True
+
+
+def test_leaf_boxes_are_the_reference_leaf_boxes(built):
+    g, ref, w = built
+    ref_leaf = ref[(ref[:, 3] >> 28) == 0]
+    by_tri = np.zeros((len(g.mesh.triangles), 3), dtype=np.uint32)
+    by_tri[ref_leaf[:, 3] & 0x0FFFFFFF] = ref_leaf[:, :3]
+    ent = w['wnodes'].reshape(-1, 4)
+    leaf = ent[(ent[:, 3] & LEAF != 0) & (ent[:, 3] != EMPTY)]
+    tri = w['record_to_tri'][leaf[:, 3] & 0x7FFFFFFF]
+    assert np.array_equal(leaf[:, :3], by_tri[tri])
+
+
+def test_inner_entries_bound_their_node(built):
+    g, ref, w = built
+    wn = w['wnodes']
+    nwide = len(wn)
+    seen = np.zeros(nwide, dtype=bool)
+    seen[0] = True
+    for i in range(nwide):
+        for e in wn[i]:
+            if e[3] == EMPTY or e[3] & LEAF:
+                continue
+            c = int(e[3])
+            assert i < c < nwide and not seen[c]        # a tree, stored parents first
+            seen[c] = True
+            lo, hi = _lo_hi(e[None, :])
+            child = wn[c][wn[c][:, 3] != EMPTY]
+            clo, chi = _lo_hi(child)
+            assert (clo >= lo).all() and (chi <= hi).all()
+        if i > 3000:
+            break
+    if nwide <= 3000:
+        assert seen.all()
+    # fill: the collapse should leave few slots empty
+    fill = (wn[:, :, 3] != EMPTY).sum() / float(nwide)
+    assert fill > 4.0
+
+
+def test_rank_is_the_reference_test_order(built):
+    g, ref, w = built
+    order = oracle.reference_test_order(ref)
+    nt = len(g.mesh.triangles)
+    assert len(order) == nt
+    expect = np.empty(nt, dtype=np.uint32)
+    expect[order] = np.arange(nt, dtype=np.uint32)
+    assert np.array_equal(w['rank'], expect)
+
+
+def test_unlayered_and_overwide_trees():
+    # hand-made tree: root with 10 children (wider than a wide node), two of them inner, stored out of layer order
+    def node(lo, hi, child, nchild):
+        return [lo | hi << 16] * 3 + [nchild << 28 | child]
+    nodes = [node(0, 100, 1, 10)]
+    tri = 0
+    for k in range(10):
+        if k in (2, 7):
+            nodes.append(None)
+        else:
+            nodes.append(node(10 * k, 10 * k + 5, tri, 0)); tri += 1
+    # inner child 2 -> nodes 11..12 ; its first child is inner again -> 13..14 (not layer order: child 7's range comes last)
+    nodes[3] = node(20, 29, 11, 2)
+    nodes.append(node(20, 24, 13, 2)); nodes.append(node(25, 29, tri, 0)); tri += 1
+    nodes.append(node(20, 21, tri, 0)); tri += 1
+    nodes.append(node(22, 24, tri, 0)); tri += 1
+    nodes[8] = node(70, 79, 15, 2)
+    nodes.append(node(70, 72, tri, 0)); tri += 1
+    nodes.append(node(75, 79, tri, 0)); tri += 1
+    ref = np.array(nodes, dtype=np.uint32)
+    w = _lib.wide_build(ref, tri)
+    order = oracle.reference_test_order(ref)
+    expect = np.empty(tri, dtype=np.uint32)
+    expect[order] = np.arange(tri, dtype=np.uint32)
+    assert np.array_equal(w['rank'], expect)
+    ent = w['wnodes'].reshape(-1, 4)
+    leaf = ent[(ent[:, 3] & LEAF != 0) & (ent[:, 3] != EMPTY)]
+    assert np.array_equal(np.sort(w['record_to_tri'][leaf[:, 3] & 0x7FFFFFFF]), np.arange(tri))
+    assert (w['wnodes'][0][:, 3] != EMPTY).sum() == 8          # 7 children + the tail of the over-wide range
+
+
+def test_malformed_tree_is_rejected():
+    bad = np.array([[0, 0, 0, 2 << 28 | 5]], dtype=np.uint32)          # children outside the array
+    with pytest.raises(_lib.ChromaError):
+        _lib.wide_build(bad, 1)
