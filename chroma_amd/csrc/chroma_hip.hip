@@ -56,7 +56,11 @@ struct chroma_ctx {
     int persistent_waves = 256 * 20 * 4;   // grid of the persistent ray-cast kernel (set from the device at init)
     int wide_waves = 256 * 14;             // same for k_raycast_wide (11 KB of LDS per wave)
     uint2 *wide_spill = nullptr;           // [wide_waves][WIDE_SPILL][64] stack entries beyond the LDS part
-    int wide_walk = 1;                     // 0 (CHROMA_WALK=reference): ray cast over the reference tree only
+    int coop_waves = 256 * 32;             // grid of k_raycast_coop (2 KB of LDS per wave: wave slots limit residency)
+    uint2 *coop_spill = nullptr;           // [coop_waves][8][COOP_SPILL]
+    int ray_chunk = 256, coop_chunk = 64;  // rays a persistent wave takes from the queue per atomic (big batches)
+    int split_tail = 1;                    // 0 (CHROMA_TAIL=fused): the last launch of chroma_propagate is the fused kernel
+    int wide_walk = 2;                     // CHROMA_WALK_*: 0 reference tree, 1 wide tree one lane per ray, 2 wide tree 8 lanes per ray
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
 };
 
@@ -248,7 +252,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
 k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
                      int32_t *hit_triangle, float *hit_distance, uint32_t *work_counter, uint32_t *retry_counter,
-                     DeviceCounters *counters)
+                     DeviceCounters *counters, int renorm)
 {
     __shared__ uint32_t s_lds[(RAY_LDS_STACK + TRAV_PENDING) * PROP_BLOCK];
     uint32_t *stack = s_lds + threadIdx.x;
@@ -286,7 +290,7 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, int nthreads, c
                     if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
                         origin = load3(pv.pos, photon_id);
                         direction = load3(pv.dir, photon_id);
-                        direction = direction / norm(direction);
+                        if (renorm) direction = direction / norm(direction);
                         if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
                             result = HIT_NAN;
                         } else {
@@ -436,7 +440,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
 k_raycast_wide(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
                int32_t *hit_triangle, float *hit_distance, uint32_t *work_counter, uint32_t *retry_counter,
-               uint2 *spill_base, DeviceCounters *counters)
+               uint2 *spill_base, DeviceCounters *counters, int renorm, int chunk)
 {
     static_assert(WIDE_FLUSH - 1 + 8 <= WIDE_PENDING, "a node visit must fit the FIFO");
     static_assert(PROP_BLOCK == WAVE, "one wave per workgroup: blockIdx.x names the wave's spill area");
@@ -459,27 +463,36 @@ k_raycast_wide(GeoView g, PhotonView pv, int first_photon, int nthreads, const u
     float min_distance = -1.0f;
     uint32_t cur = WIDE_NONE;
     int sp = 0, npend = 0;
+    // the wave's share of the queue, [loc_next, loc_end), taken `chunk` rays per atomic: a hot word
+    // serves only ~88 atomics/us, far fewer than the refills 1e8 rays need
+    uint32_t loc_next = 0, loc_end = 0;
     bool exhausted = false;
 
     for (;;) {
         // ---- refill idle lanes
         unsigned long long idle_mask = __ballot(!has_ray);
         int n_idle = __popcll(idle_mask);
-        if (!exhausted && (n_idle >= RAY_REFILL_MIN || n_idle == WAVE)) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(work_counter, (uint32_t)n_idle);
-            base = __shfl(base, 0);
-            if (base + (uint32_t)n_idle >= (uint32_t)nthreads) exhausted = true;
+        bool more = !exhausted || loc_next < loc_end;
+        if (more && (n_idle >= RAY_REFILL_MIN || n_idle == WAVE)) {
+            if (loc_next >= loc_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work_counter, (uint32_t)chunk);
+                base = __shfl(base, 0);
+                if (base + (uint32_t)chunk >= (uint32_t)nthreads) exhausted = true;
+                loc_next = min(base, (uint32_t)nthreads);
+                loc_end = min(base + (uint32_t)chunk, (uint32_t)nthreads);
+            }
+            uint32_t idx = loc_next + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+            loc_next = min(loc_end, loc_next + (uint32_t)n_idle);
             if (!has_ray) {
-                uint32_t idx = base + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-                if (idx < (uint32_t)nthreads) {
+                if (idx < loc_end) {
                     slot = first_photon + (int)idx;
                     uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
                     int result = HIT_SKIP;
                     if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
                         origin = load3(pv.pos, photon_id);
                         direction = load3(pv.dir, photon_id);
-                        direction = direction / norm(direction);
+                        if (renorm) direction = direction / norm(direction);
                         if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
                             result = HIT_NAN;
                         } else {
@@ -514,12 +527,13 @@ k_raycast_wide(GeoView g, PhotonView pv, int first_photon, int nthreads, const u
             }
         }
         if (!__any(has_ray)) {
-            if (exhausted) break;
+            if (exhausted && loc_next >= loc_end) break;
             continue;
         }
 
         // ---- node phase: one wide node per active lane per iteration
-        const int stop_at = exhausted ? 0 : max(0, __popcll(__ballot(active)) - RAY_REFILL_MIN);
+        more = !exhausted || loc_next < loc_end;
+        const int stop_at = more ? max(0, __popcll(__ballot(active)) - RAY_REFILL_MIN) : 0;
         do {
             if (active && cur == WIDE_NONE) {
                 // next entry that can still hold a nearer hit
@@ -614,13 +628,257 @@ k_raycast_wide(GeoView g, PhotonView pv, int first_photon, int nthreads, const u
     }
 }
 
+// ---- cooperative ray cast over the 8-wide tree: eight lanes per ray ---------------------------------
+// A wavefront carries 8 rays; the 8 lanes of a group each own ONE of the eight child entries of the
+// node their ray is visiting.  A node visit is therefore one coalesced 128-byte read per group (one
+// dwordx4 per lane, 8 lines per wave instruction instead of 64), one slab test per lane, and a few
+// group-wide operations: ballots give the set of children hit, DPP min-reductions pick the nearest
+// inner child, and every other hit lane writes its own (node, distance) entry at its own stack slot,
+// so nothing in the visit is serial.  Triangle tests are shared the same way: up to 8 postponed
+// triangles of a ray are tested at once, one per lane, and reduced by (distance, rank).
+// The per-ray state (origin, direction, slab constants, best hit, stack pointer) is replicated in
+// the 8 lanes of the group and stays identical because every lane computes it from the same
+// ballots and broadcasts.  LDS: 8 groups x (24 stack entries + 16 postponed triangles) = 2 KB per
+// wave, so residency is limited by wave slots only.  Results are those of k_raycast_wide (and of
+// the reference): same conservative tree, same tie-break.
+#ifndef COOP_STACK
+#define COOP_STACK 24
+#endif
+#define COOP_PENDING 16
+#define COOP_STRIDE (2 * COOP_STACK + COOP_PENDING + 1)     // words per group, +1 staggers the banks
+#ifndef COOP_SPILL
+#define COOP_SPILL 104       // stack entries per ray beyond the LDS part (global memory)
+#endif
+#ifndef COOP_REFILL_MIN
+#define COOP_REFILL_MIN 2    // refill once this many of the 8 groups are idle
+#endif
+
+// group-wide (8 lanes) minimum with DPP: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror;
+// every lane of the group ends with the result
+__device__ inline float group8_min(float v)
+{
+    v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+    v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+    v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
+    return v;
+}
+__device__ inline uint32_t group8_min_u32(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));
+    return v;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK) void
+k_raycast_coop(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
+               int32_t *hit_triangle, float *hit_distance, uint32_t *work_counter, uint32_t *retry_counter,
+               uint2 *spill_base, DeviceCounters *counters, int renorm, int chunk)
+{
+    static_assert(PROP_BLOCK == WAVE, "one wave per workgroup");
+    __shared__ uint32_t s_lds[8 * COOP_STRIDE];
+    const unsigned lane = lane_id();
+    const unsigned j = lane & 7u, gshift = lane & ~7u, grp = lane >> 3;
+    const uint32_t below = (1u << j) - 1u;
+    uint32_t *stack_n = s_lds + grp * COOP_STRIDE;
+    float *stack_t = (float *)(stack_n + COOP_STACK);
+    uint32_t *pending = stack_n + 2 * COOP_STACK;
+    uint2 *spill = spill_base + ((size_t)blockIdx.x * 8 + grp) * COOP_SPILL;
+    LaneCounters cnt = {0, 0, 0, 0};
+    const float inf = cm_inff();
+
+    // per-ray state, identical in the 8 lanes of a group
+    bool has_ray = false, active = false;
+    int slot = 0;
+    v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
+    RayFast rf;
+    rf.a = rf.blo = rf.bhi = mk3(0.f, 0.f, 0.f);
+    int last_hit = -1, triangle_index = -1;
+    uint32_t best_rank = 0;
+    float min_distance = -1.0f;
+    uint32_t cur = WIDE_NONE;
+    int sp = 0, npend = 0;
+    // the wave's share of the queue: [loc_next, loc_end) taken `chunk` rays at a time
+    uint32_t loc_next = 0, loc_end = 0;
+    bool exhausted = false;
+
+    for (;;) {
+        // ---- refill idle groups
+        unsigned long long idle_mask = __ballot(!has_ray && j == 0);
+        int n_idle = __popcll(idle_mask);
+        bool more = !exhausted || loc_next < loc_end;
+        if (more && (n_idle >= COOP_REFILL_MIN || n_idle == 8)) {
+            if (loc_next >= loc_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work_counter, (uint32_t)chunk);
+                base = __shfl(base, 0);
+                if (base + (uint32_t)chunk >= (uint32_t)nthreads) exhausted = true;
+                loc_next = min(base, (uint32_t)nthreads);
+                loc_end = min(base + (uint32_t)chunk, (uint32_t)nthreads);
+            }
+            uint32_t idx = loc_next + (uint32_t)__popcll(idle_mask & ((1ull << gshift) - 1ull));
+            loc_next = min(loc_end, loc_next + (uint32_t)n_idle);
+            if (!has_ray && idx < loc_end) {
+                slot = first_photon + (int)idx;
+                uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
+                int result = HIT_SKIP;
+                if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
+                    origin = load3(pv.pos, photon_id);
+                    direction = load3(pv.dir, photon_id);
+                    if (renorm) direction = direction / norm(direction);
+                    if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
+                        result = HIT_NAN;
+                    } else {
+                        v3 noid = (-origin) / direction;
+                        v3 inv_dir = 1.0f / direction;
+                        bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                                        cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+                        if (!moderate) {
+                            result = HIT_RETRY;
+                        } else {
+                            if (COUNT && j == 0) cnt.steps++;
+                            rf = ray_fast(g, noid, inv_dir);
+                            last_hit = pv.last_hit_triangles[photon_id];
+                            if (last_hit >= 0) last_hit = (int)g.tri_to_dev[last_hit];
+                            triangle_index = -1;
+                            min_distance = -1.0f;
+                            sp = 0;
+                            npend = 0;
+                            cur = 0;
+                            has_ray = true;
+                            active = true;
+                            result = 0;
+                        }
+                    }
+                }
+                if (!has_ray && j == 0) {
+                    hit_triangle[slot] = result;
+                    hit_distance[slot] = 0.0f;
+                    if (result == HIT_RETRY) atomicAdd(retry_counter, 1u);
+                }
+            }
+        }
+        if (!__any(has_ray)) {
+            if (exhausted && loc_next >= loc_end) break;
+            continue;
+        }
+
+        // ---- node phase: every active group visits one node per iteration
+        more = !exhausted || loc_next < loc_end;
+        const int stop_at = more ? max(0, __popcll(__ballot(active && j == 0)) - COOP_REFILL_MIN) : 0;
+        do {
+            if (active && cur == WIDE_NONE) {
+                // next entry that can still hold a nearer hit
+                while (sp > 0) {
+                    sp--;
+                    uint32_t n; float t;
+                    if (sp < COOP_STACK) { n = stack_n[sp]; t = stack_t[sp]; }
+                    else { uint2 e = spill[sp - COOP_STACK]; n = e.x; t = __uint_as_float(e.y); }
+                    if (min_distance < 0.0f || !(t > min_distance)) { cur = n; break; }
+                }
+                if (cur == WIDE_NONE) active = false;
+            }
+            if (active) {
+                const uint4 e = g.wnodes[8 * (size_t)cur + j];
+                if (COUNT && j == 0) cnt.nodes += 8;
+                const float t = box_tmin_fast(rf, e);
+                const uint32_t w = e.w;
+                const bool pass = (w != WIDE_NONE) && node_passes(t, min_distance);
+                const bool isleaf = (w & 0x80000000u) != 0u;
+                const bool leaf = pass && isleaf && (int)(w & 0x7FFFFFFFu) != last_hit;
+                const bool inner = pass && !isleaf;
+                const uint32_t gl = (uint32_t)(__ballot(leaf) >> gshift) & 0xFFu;
+                const uint32_t gi = (uint32_t)(__ballot(inner) >> gshift) & 0xFFu;
+                if (leaf) pending[npend + __popc(gl & below)] = w & 0x7FFFFFFFu;
+                npend += __popc(gl);
+                cur = WIDE_NONE;
+                if (gi) {
+                    const float tm = group8_min(inner ? t : inf);
+                    const uint32_t gn = (uint32_t)(__ballot(inner && t == tm) >> gshift) & 0xFFu;
+                    const uint32_t nj = (uint32_t)__ffs((int)gn) - 1u;          // lane of the nearest inner child
+                    const uint32_t others = gi & ~(1u << nj);
+                    if (inner && j != nj) {
+                        int pos = sp + __popc(others & below);
+                        if (pos < COOP_STACK) { stack_n[pos] = w; stack_t[pos] = t; }
+                        else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(w, __float_as_uint(t));
+                    }
+                    sp += __popc(others);
+                    cur = (uint32_t)__shfl((int)w, (int)(gshift + nj));
+                    if (sp > COOP_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
+                        if (COUNT && j == 0) cnt.steps--;         // counted again by the retry pass
+                        triangle_index = HIT_RETRY;
+                        active = false; npend = 0; cur = WIDE_NONE; sp = 0;
+                    }
+                }
+            }
+        } while (!__any(npend >= 8) && __popcll(__ballot(active && j == 0)) > stop_at);
+        __builtin_amdgcn_wave_barrier();      // (scheduling fence: the lanes of a group exchange data through LDS)
+
+        // ---- leaf phase: up to 8 postponed triangles of a ray at once, one per lane
+        while (__any(npend > 0)) {
+            if (npend > 0) {
+                const int take = min(npend, 8);
+                bool hit = false;
+                float distance = inf;
+                uint32_t tri = 0, rank = 0xFFFFFFFFu;
+                if ((int)j < take) {
+                    tri = pending[j];
+                    if (COUNT) cnt.tris++;
+                    const float4 *tp = g.tri + 3 * (size_t)tri;
+                    float4 a = tp[0], b = tp[1], c = tp[2];
+                    hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
+                    rank = __float_as_uint(c.w);
+                }
+                const float dm = group8_min(hit ? distance : inf);
+                if (dm < inf) {
+                    const bool cand = hit && distance == dm;
+                    const uint32_t rm = group8_min_u32(cand ? rank : 0xFFFFFFFFu);
+                    const uint32_t gw = (uint32_t)(__ballot(cand && rank == rm) >> gshift) & 0xFFu;
+                    const uint32_t wj = (uint32_t)__ffs((int)gw) - 1u;
+                    const int wtri = __shfl((int)tri, (int)(gshift + wj));
+                    if (triangle_index == -1 || dm < min_distance || (dm == min_distance && rm < best_rank)) {
+                        triangle_index = wtri;
+                        min_distance = dm;
+                        best_rank = rm;
+                    }
+                }
+                if (npend > 8) {                      // keep the rest: move entries 8.. down
+                    uint32_t mv = pending[j + 8];
+                    if ((int)j + 8 < npend) pending[j] = mv;
+                }
+                npend -= take;
+            }
+        }
+
+        // ---- retire finished rays
+        if (has_ray && !active) {
+            if (j == 0) {
+                hit_triangle[slot] = (triangle_index >= 0) ? (int)g.dev_to_tri[triangle_index] : triangle_index;
+                hit_distance[slot] = min_distance;
+                if (triangle_index == HIT_RETRY) atomicAdd(retry_counter, 1u);
+            }
+            has_ray = false;
+        }
+    }
+
+    if (COUNT) {
+        unsigned long long st = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        if (lane == 0) {
+            atomicAdd(&counters->photon_steps, st);
+            atomicAdd(&counters->nodes_visited, nd);
+            atomicAdd(&counters->triangles_tested, tr);
+        }
+    }
+}
+
 // Second pass for the slots k_raycast_persistent marked HIT_RETRY (normally none): the general
 // walk (reference-exact slab test, stack spilling to scratch).  A small fixed grid strides over
 // the queue; it returns at once when the retry counter is zero.
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
 k_raycast_retry(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
-                int32_t *hit_triangle, float *hit_distance, const uint32_t *retry_counter, DeviceCounters *counters)
+                int32_t *hit_triangle, float *hit_distance, const uint32_t *retry_counter, DeviceCounters *counters, int renorm)
 {
     __shared__ uint32_t s_lds[TRAV_LDS_WORDS(STACK_LDS, PROP_BLOCK)];
     if (*retry_counter == 0u) return;
@@ -635,7 +893,7 @@ k_raycast_retry(GeoView g, PhotonView pv, int first_photon, int nthreads, const 
             uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
             position = load3(pv.pos, photon_id);
             direction = load3(pv.dir, photon_id);
-            direction = direction / norm(direction);
+            if (renorm) direction = direction / norm(direction);
             last_hit = pv.last_hit_triangles[photon_id];
             cast = true;
             if (COUNT) cnt.steps++;
@@ -664,7 +922,7 @@ k_raycast_retry(GeoView g, PhotonView pv, int first_photon, int nthreads, const 
 __global__ __launch_bounds__(PHYS_BLOCK) void
 k_physics(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue, uint32_t *output_queue,
           const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base, int use_weights,
-          int scatter_first)
+          int scatter_first, int renorm)
 {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     bool alive = false;
@@ -676,9 +934,11 @@ k_physics(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32
             Photon p;
             p.position = load3(pv.pos, photon_id);
             p.direction = load3(pv.dir, photon_id);
-            p.direction = p.direction / norm(p.direction);
             p.polarization = load3(pv.pol, photon_id);
-            p.polarization = p.polarization / norm(p.polarization);
+            if (renorm) {
+                p.direction = p.direction / norm(p.direction);
+                p.polarization = p.polarization / norm(p.polarization);
+            }
             p.wavelength = pv.wavelengths[photon_id];
             p.time = pv.t[photon_id];
             p.last_hit_triangle = pv.last_hit_triangles[photon_id];
@@ -1032,7 +1292,8 @@ static int launch_propagate(chroma_ctx *ctx, chroma_geometry *geom, PhotonView p
 
 // one step for many photons: ray cast and physics as two launches
 static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, int nthreads, const uint32_t *in_q,
-                             uint32_t *out_q, chroma_rng rng, int use_weights, int scatter_first, bool mark_raycast_end = false)
+                             uint32_t *out_q, chroma_rng rng, int use_weights, int scatter_first, bool mark_raycast_end = false,
+                             int renorm = 1)
 {
     if (nthreads <= 0) return CHROMA_OK;
     uint32_t need = geom->stack_need;
@@ -1041,43 +1302,50 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     // persistent ray cast: enough waves to fill the chip a few times over, each pulling rays
     // from the queue through ctx->d_words[4]; d_words[5] counts the rays left for the retry pass
     HIP_TRY(hipMemsetAsync(ctx->d_words + 4, 0, 8, ctx->stream));
-    const bool wide = ctx->wide_walk && geom->view.wnodes && geom->wide_stack_need <= WIDE_STACK + WIDE_SPILL;
+    const bool have_wide = geom->view.wnodes != nullptr;
+    const bool coop = ctx->wide_walk == CHROMA_WALK_COOP && have_wide && geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
+    const bool wide = !coop && ctx->wide_walk != CHROMA_WALK_REFERENCE && have_wide && geom->wide_stack_need <= WIDE_STACK + WIDE_SPILL;
     if (wide && !ctx->wide_spill) {
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipMalloc((void **)&ctx->wide_spill, (size_t)ctx->wide_waves * WIDE_SPILL * PROP_BLOCK * sizeof(uint2)));
     }
-    unsigned waves = (unsigned)std::min<long long>(((long long)nthreads + PROP_BLOCK - 1) / PROP_BLOCK,
-                                                   (long long)(wide ? ctx->wide_waves : ctx->persistent_waves));
-    dim3 grid(waves), block(PROP_BLOCK);
-    if (wide) {
-        if (ctx->counting)
-            hipLaunchKernelGGL((k_raycast_wide<true>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
-                               ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 4, ctx->d_words + 5, ctx->wide_spill, ctx->d_counters);
-        else
-            hipLaunchKernelGGL((k_raycast_wide<false>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
-                               ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 4, ctx->d_words + 5, ctx->wide_spill, ctx->d_counters);
-        if (mark_raycast_end) HIP_TRY(hipEventRecord(ctx->ev_mid, ctx->stream));
-        if (ctx->counting)
-            hipLaunchKernelGGL((k_raycast_retry<true>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
-                               ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
-        else
-            hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
-                               ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
-    } else if (ctx->counting) {
-        hipLaunchKernelGGL((k_raycast_persistent<true>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 4, ctx->d_words + 5, ctx->d_counters);
-        if (mark_raycast_end) HIP_TRY(hipEventRecord(ctx->ev_mid, ctx->stream));
-        hipLaunchKernelGGL((k_raycast_retry<true>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
-    } else {
-        hipLaunchKernelGGL((k_raycast_persistent<false>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 4, ctx->d_words + 5, ctx->d_counters);
-        if (mark_raycast_end) HIP_TRY(hipEventRecord(ctx->ev_mid, ctx->stream));
-        hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->d_words + 5, ctx->d_counters);
+    if (coop && !ctx->coop_spill) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, (size_t)ctx->coop_waves * 8 * COOP_SPILL * sizeof(uint2)));
     }
+    // rays a wave takes from the queue per atomic: many for big batches (a hot word serves only
+    // ~88 atomics/us), one wave-load when every wave gets only a few rounds anyway
+    unsigned waves;
+    int chunk;
+    if (coop) {
+        waves = (unsigned)std::min<long long>(((long long)nthreads + 7) / 8, (long long)ctx->coop_waves);
+        chunk = ((long long)nthreads > 4ll * ctx->coop_chunk * ctx->coop_waves) ? ctx->coop_chunk : 8;
+    } else {
+        waves = (unsigned)std::min<long long>(((long long)nthreads + PROP_BLOCK - 1) / PROP_BLOCK,
+                                              (long long)(wide ? ctx->wide_waves : ctx->persistent_waves));
+        chunk = ((long long)nthreads > 4ll * ctx->ray_chunk * ctx->wide_waves) ? ctx->ray_chunk : PROP_BLOCK;
+    }
+    dim3 grid(waves), block(PROP_BLOCK);
+    uint32_t *work = ctx->d_words + 4, *retry = ctx->d_words + 5;
+#define RAYCAST_LAUNCH(COUNT)                                                                                          \
+    do {                                                                                                               \
+        if (coop)                                                                                                      \
+            hipLaunchKernelGGL((k_raycast_coop<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q, \
+                               ctx->hit_triangle, ctx->hit_distance, work, retry, ctx->coop_spill, ctx->d_counters, renorm, chunk); \
+        else if (wide)                                                                                                 \
+            hipLaunchKernelGGL((k_raycast_wide<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q, \
+                               ctx->hit_triangle, ctx->hit_distance, work, retry, ctx->wide_spill, ctx->d_counters, renorm, chunk); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_raycast_persistent<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, \
+                               in_q, ctx->hit_triangle, ctx->hit_distance, work, retry, ctx->d_counters, renorm);       \
+        if (mark_raycast_end) HIP_TRY(hipEventRecord(ctx->ev_mid, ctx->stream));                                        \
+        hipLaunchKernelGGL((k_raycast_retry<COUNT>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q, \
+                           ctx->hit_triangle, ctx->hit_distance, retry, ctx->d_counters, renorm);                       \
+    } while (0)
+    if (ctx->counting) RAYCAST_LAUNCH(true); else RAYCAST_LAUNCH(false);
+#undef RAYCAST_LAUNCH
     hipLaunchKernelGGL(k_physics, dim3((unsigned)((nthreads + PHYS_BLOCK - 1) / PHYS_BLOCK)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, 0, nthreads,
-                       in_q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first);
+                       in_q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first, renorm);
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
 }
@@ -1167,7 +1435,14 @@ int chroma_init(int device, chroma_ctx **out)
         int wide_per_cu = 14;                // LDS-limited residency of k_raycast_wide
         if (const char *e = getenv("CHROMA_WIDE_WAVES_PER_CU")) wide_per_cu = std::max(1, atoi(e));
         ctx->wide_waves = prop.multiProcessorCount * wide_per_cu;
-        if (const char *e = getenv("CHROMA_WALK")) ctx->wide_walk = (strcmp(e, "reference") != 0);
+        int coop_per_cu = 24;                // 74 VGPRs: 6 waves per SIMD
+        if (const char *e = getenv("CHROMA_COOP_WAVES_PER_CU")) coop_per_cu = std::max(1, atoi(e));
+        ctx->coop_waves = prop.multiProcessorCount * coop_per_cu;
+        if (const char *e = getenv("CHROMA_WALK"))
+            ctx->wide_walk = !strcmp(e, "reference") ? CHROMA_WALK_REFERENCE : !strcmp(e, "wide") ? CHROMA_WALK_WIDE : CHROMA_WALK_COOP;
+        if (const char *e = getenv("CHROMA_RAY_CHUNK")) ctx->ray_chunk = std::max(64, atoi(e));
+        if (const char *e = getenv("CHROMA_COOP_CHUNK")) ctx->coop_chunk = std::max(8, atoi(e));
+        if (const char *e = getenv("CHROMA_TAIL")) ctx->split_tail = (strcmp(e, "fused") != 0);
     }
     HIP_TRY(hipEventCreate(&ctx->ev_start));
     HIP_TRY(hipEventCreate(&ctx->ev_stop));
@@ -1184,6 +1459,7 @@ int chroma_shutdown(chroma_ctx *ctx)
     if (ctx->queue_a) hipFree(ctx->queue_a);
     if (ctx->queue_b) hipFree(ctx->queue_b);
     if (ctx->wide_spill) hipFree(ctx->wide_spill);
+    if (ctx->coop_spill) hipFree(ctx->coop_spill);
     if (ctx->hit_triangle) hipFree(ctx->hit_triangle);
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
     hipFree(ctx->d_counters);
@@ -1656,8 +1932,9 @@ int chroma_set_counting(chroma_ctx *ctx, int32_t enabled)
 int chroma_set_walk(chroma_ctx *ctx, int32_t mode)
 {
     if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
-    if (mode != CHROMA_WALK_REFERENCE && mode != CHROMA_WALK_WIDE) return set_error(CHROMA_ERR_INVALID, "unknown walk mode %d", mode);
-    ctx->wide_walk = (mode == CHROMA_WALK_WIDE);
+    if (mode != CHROMA_WALK_REFERENCE && mode != CHROMA_WALK_WIDE && mode != CHROMA_WALK_COOP)
+        return set_error(CHROMA_ERR_INVALID, "unknown walk mode %d", mode);
+    ctx->wide_walk = mode;
     return CHROMA_OK;
 }
 
@@ -1685,23 +1962,36 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     uint64_t launches = 0, raycast_launches = 0;
     uint64_t n = nphotons;
     int step = 0;
+    // Launch policy of the reference (chroma/gpu/photon.py:225-252): one step per launch while many
+    // photons are alive, and ONE launch for all remaining steps once fewer than 64*16*8 are left (or
+    // with weights).  A launch re-normalises dir/pol when it loads a photon (propagate.cu:248,250), so
+    // the policy is part of the arithmetic.  Here that last launch is either the fused kernel, or
+    // (default without weights) a run of one-step launches that skip the re-normalisation after
+    // their first: same numbers, but every step gets the whole chip instead of < 128 waves.
+    bool in_tail = false;
     while (step < max_steps) {
-        // finish in one launch once few photons are left (chroma/gpu/photon.py:227-230)
-        int nsteps = (n < (uint64_t)PROP_BLOCK * 16 * 8 || use_weights) ? (max_steps - step) : 1;
+        const bool few = n < (uint64_t)PROP_BLOCK * 16 * 8;
+        const bool fused = use_weights || (few && !ctx->split_tail);
+        int nsteps = fused ? (max_steps - step) : 1;
+        int renorm = 1;
+        if (!fused) {
+            if (in_tail) renorm = 0;
+            else if (few) in_tail = true;
+        }
         if (time_kernels) HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-        if (nsteps == 1)
-            rc = launch_split_step(ctx, geom, pv, (int)n, in_q + 1, out_q, rng, use_weights, scatter_first, time_kernels != 0);
+        if (!fused)
+            rc = launch_split_step(ctx, geom, pv, (int)n, in_q + 1, out_q, rng, use_weights, scatter_first, time_kernels != 0, renorm);
         else
             rc = launch_propagate(ctx, geom, pv, 0, (int)n, in_q + 1, out_q, rng, nsteps, use_weights, scatter_first);
         if (rc) return rc;
-        launches++;
+        if (renorm) launches++;          // launches in the reference's sense
         if (time_kernels) {
             HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
             HIP_TRY(hipEventSynchronize(ctx->ev_stop));
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
             kernel_ms += ms;
-            if (nsteps == 1) {
+            if (!fused) {
                 HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_mid));
                 raycast_ms += ms;
                 raycast_launches++;
