@@ -1602,7 +1602,7 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     chroma_host::WideTree wt;
     {
         std::string werr;
-        if (chroma_host::build_wide_tree(d->nodes, d->nnodes, d->ntriangles, wt, werr) != 0) {
+        if (chroma_host::build_wide_tree(d->nodes, d->nnodes, d->ntriangles, wt, werr, chroma_host::wide_topology_from_env()) != 0) {
             chroma_geometry_destroy(g);
             return set_error(CHROMA_ERR_INVALID, "%s", werr.c_str());
         }

@@ -8,6 +8,9 @@
 namespace chroma_host {
 
 enum : uint32_t { WIDE_K = 8, WIDE_LEAF = 0x80000000u, WIDE_EMPTY = 0xFFFFFFFFu };
+// how the hierarchy above the reference's leaf boxes is chosen
+enum { WIDE_TOPOLOGY_COLLAPSE = 0,     // the reference tree with children pulled up until a node has eight
+       WIDE_TOPOLOGY_SAH = 1 };        // rebuilt with binned surface-area-heuristic splits (default)
 
 struct WideTree {
     std::vector<uint32_t> wnodes;       // nwide * 8 entries of 4 words: x, y, z boxes, w = child (see above)
@@ -21,6 +24,9 @@ struct WideTree {
 
 // nodes: reference-format BVH (4 words per node, root first, children of a node contiguous and
 // stored after every node of their parent's layer).  Returns 0, or -1 with `err` set.
-int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, WideTree &out, std::string &err);
+int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, WideTree &out, std::string &err,
+                    int topology = WIDE_TOPOLOGY_SAH);
+// CHROMA_TREE=collapse|sah (default sah)
+int wide_topology_from_env();
 
 }  // namespace chroma_host

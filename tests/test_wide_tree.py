@@ -1,6 +1,9 @@
-"""The derived 8-wide traversal tree (chroma_amd/csrc/wide_build.cpp): structure invariants and the
-reference test-order ranks, checked against the oracle's replay of the reference loop
+"""The derived 8-wide traversal tree (chroma_amd/csrc/wide_build.cpp), in both topologies -- the
+collapsed reference tree and the SAH rebuild over the reference's leaf boxes: structure invariants
+and the reference test-order ranks, checked against the oracle's replay of the reference loop
 (chroma/cuda/mesh.h:58-110).  Host code only -- no GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -21,12 +24,27 @@ def _geometries():
     yield 'tiny', create_geometry_from_obj(demo.tiny())
 
 
-@pytest.fixture(scope='module', params=['cube', 'tiny'])
+def _wide(nodes, ntriangles, topology):
+    old = os.environ.get('CHROMA_TREE')
+    os.environ['CHROMA_TREE'] = topology
+    try:
+        return _lib.wide_build(nodes, ntriangles)
+    finally:
+        if old is None:
+            del os.environ['CHROMA_TREE']
+        else:
+            os.environ['CHROMA_TREE'] = old
+
+
+@pytest.fixture(scope='module', params=['cube-collapse', 'cube-sah', 'tiny-collapse', 'tiny-sah'])
 def built(request):
+    want, topology = request.param.split('-')
     for name, g in _geometries():
-        if name == request.param:
+        if name == want:
             nodes = np.ascontiguousarray(g.bvh.nodes)
-            return g, nodes.view(np.uint32).reshape(-1, 4), _lib.wide_build(nodes, len(g.mesh.triangles))
+            w = _wide(nodes, len(g.mesh.triangles), topology)
+            w['topology'] = topology
+            return g, nodes.view(np.uint32).reshape(-1, 4), w
 
 
 def _lo_hi(words):
@@ -43,10 +61,11 @@ def test_every_triangle_is_one_record(built):
     ent = w['wnodes'].reshape(-1, 4)
     leaf = ent[(ent[:, 3] & LEAF != 0) & (ent[:, 3] != EMPTY)]
     assert np.array_equal(np.sort(leaf[:, 3] & 0x7FFFFFFF), np.arange(nt))      # each record under exactly one entry
-    # triangle children of a node are consecutive records
-    for node in w['wnodes'][:2000]:
-        recs = [int(e[3] & 0x7FFFFFFF) for e in node if e[3] != EMPTY and e[3] & LEAF]
-        assert recs == list(range(recs[0], recs[0] + len(recs))) if recs else True
+    if w['topology'] == 'collapse':
+        # triangle children of a node are consecutive records
+        for node in w['wnodes'][:2000]:
+            recs = [int(e[3] & 0x7FFFFFFF) for e in node if e[3] != EMPTY and e[3] & LEAF]
+            assert recs == list(range(recs[0], recs[0] + len(recs))) if recs else True
 
 
 def test_leaf_boxes_are_the_reference_leaf_boxes(built):
@@ -81,9 +100,9 @@ def test_inner_entries_bound_their_node(built):
             break
     if nwide <= 3000:
         assert seen.all()
-    # fill: the collapse should leave few slots empty
+    # few slots stay empty
     fill = (wn[:, :, 3] != EMPTY).sum() / float(nwide)
-    assert fill > 4.0
+    assert fill > (4.0 if nwide > 10 else 1.0)
 
 
 def test_rank_is_the_reference_test_order(built):
@@ -116,7 +135,11 @@ def test_unlayered_and_overwide_trees():
     nodes.append(node(70, 72, tri, 0)); tri += 1
     nodes.append(node(75, 79, tri, 0)); tri += 1
     ref = np.array(nodes, dtype=np.uint32)
-    w = _lib.wide_build(ref, tri)
+    for topology in ('sah', 'collapse'):
+        w = _wide(ref, tri, topology)
+        ent = w['wnodes'].reshape(-1, 4)
+        leaf = ent[(ent[:, 3] & LEAF != 0) & (ent[:, 3] != EMPTY)]
+        assert np.array_equal(np.sort(w['record_to_tri'][leaf[:, 3] & 0x7FFFFFFF]), np.arange(tri))
     order = oracle.reference_test_order(ref)
     expect = np.empty(tri, dtype=np.uint32)
     expect[order] = np.arange(tri, dtype=np.uint32)
