@@ -39,6 +39,16 @@ static int set_error(int code, const char *fmt, ...)
             return set_error((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+struct StepState {
+    uint32_t n;          // photons queued for this step
+    uint32_t renorm;     // this step opens a launch in the reference's sense: re-normalise dir/pol on load
+    uint32_t in_tail;    // the reference's last launch (all remaining steps) has begun
+    uint32_t launches;   // launches in the reference's sense so far
+    uint32_t work;       // next unclaimed ray of the persistent ray cast
+    uint32_t retry;      // rays left for k_raycast_retry
+    uint32_t pad[2];
+};
+
 struct chroma_ctx {
     int device;
     hipStream_t stream;
@@ -53,6 +63,10 @@ struct chroma_ctx {
     uint32_t *d_words = nullptr;        // 16 words
     uint32_t *h_words = nullptr;        // pinned mirror
     int counting = 0;
+    StepState *d_step = nullptr;           // device-side step control block (k_step_begin)
+    uint32_t *h_step = nullptr;            // pinned copy for the occasional read-back
+    int physics_blocks = 256 * 8;          // grid cap of k_physics (blocks stride over the queue)
+    std::vector<hipEvent_t> step_events;   // 3 per step when kernels are timed
     int persistent_waves = 256 * 20 * 4;   // grid of the persistent ray-cast kernel (set from the device at init)
     int wide_waves = 256 * 14;             // same for k_raycast_wide (11 KB of LDS per wave)
     uint2 *wide_spill = nullptr;           // [wide_waves][WIDE_SPILL][64] stack entries beyond the LDS part
@@ -232,6 +246,26 @@ k_raycast(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32
     if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
 }
 
+// ---- device-side step control ---------------------------------------------------------------------
+// chroma_propagate enqueues its steps without waiting for any of them: how many photons a step has
+// (the tail of its input queue), whether its launch re-normalises (the reference's launch policy,
+// chroma/gpu/photon.py:225-252) and the ray-cast work counters live in this block, written by
+// k_step_begin at the head of every step and read by the step's kernels.
+
+__global__ void k_step_begin(const uint32_t *in_queue, uint32_t *out_queue, StepState *st, uint32_t few)
+{
+    const uint32_t n = in_queue[0] - 1u;
+    st->n = n;
+    uint32_t renorm = 1u;
+    if (st->in_tail) renorm = 0u;
+    else if (n < few) st->in_tail = 1u;
+    st->renorm = renorm;
+    if (renorm && n) st->launches++;
+    st->work = 0u;
+    st->retry = 0u;
+    out_queue[0] = 1u;
+}
+
 // ---- persistent ray cast with lane refill ---------------------------------------------------------
 // One ray per lane, but a lane that finishes its ray takes the next one from the queue (one atomic
 // per wave per refill), so the 64 lanes of a wave stay busy although their rays need very
@@ -250,10 +284,12 @@ k_raycast(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32
 
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
-k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
-                     int32_t *hit_triangle, float *hit_distance, uint32_t *work_counter, uint32_t *retry_counter,
-                     DeviceCounters *counters, int renorm)
+k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
+                     int32_t *hit_triangle, float *hit_distance, DeviceCounters *counters)
 {
+    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    if ((long long)blockIdx.x * PROP_BLOCK >= nthreads) return;
+    uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
     __shared__ uint32_t s_lds[(RAY_LDS_STACK + TRAV_PENDING) * PROP_BLOCK];
     uint32_t *stack = s_lds + threadIdx.x;
     uint32_t *pending = stack + RAY_LDS_STACK * PROP_BLOCK;
@@ -438,10 +474,15 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, int nthreads, c
 
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
-k_raycast_wide(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
-               int32_t *hit_triangle, float *hit_distance, uint32_t *work_counter, uint32_t *retry_counter,
-               uint2 *spill_base, DeviceCounters *counters, int renorm, int chunk)
+k_raycast_wide(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
+               int32_t *hit_triangle, float *hit_distance, uint2 *spill_base, DeviceCounters *counters, int big_chunk)
 {
+    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    if ((long long)blockIdx.x * PROP_BLOCK >= nthreads) return;
+    uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
+    // rays taken from the queue per atomic: many for big batches (a hot word serves only ~88 atomics/us),
+    // one wave-load when every wave gets only a few rounds anyway
+    const int chunk = ((long long)nthreads > 4ll * big_chunk * (long long)gridDim.x) ? big_chunk : PROP_BLOCK;
     static_assert(WIDE_FLUSH - 1 + 8 <= WIDE_PENDING, "a node visit must fit the FIFO");
     static_assert(PROP_BLOCK == WAVE, "one wave per workgroup: blockIdx.x names the wave's spill area");
     // stack entries beyond the LDS part live in this wave's slice of a global buffer, [entry][lane]
@@ -672,10 +713,13 @@ __device__ inline uint32_t group8_min_u32(uint32_t v)
 
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
-k_raycast_coop(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
-               int32_t *hit_triangle, float *hit_distance, uint32_t *work_counter, uint32_t *retry_counter,
-               uint2 *spill_base, DeviceCounters *counters, int renorm, int chunk)
+k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
+               int32_t *hit_triangle, float *hit_distance, uint2 *spill_base, DeviceCounters *counters, int big_chunk)
 {
+    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    if ((long long)blockIdx.x * 8 >= nthreads) return;
+    uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
+    const int chunk = ((long long)nthreads > 4ll * big_chunk * (long long)gridDim.x) ? big_chunk : 8;
     static_assert(PROP_BLOCK == WAVE, "one wave per workgroup");
     __shared__ uint32_t s_lds[8 * COOP_STRIDE];
     const unsigned lane = lane_id();
@@ -877,9 +921,11 @@ k_raycast_coop(GeoView g, PhotonView pv, int first_photon, int nthreads, const u
 // the queue; it returns at once when the retry counter is zero.
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
-k_raycast_retry(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
-                int32_t *hit_triangle, float *hit_distance, const uint32_t *retry_counter, DeviceCounters *counters, int renorm)
+k_raycast_retry(GeoView g, PhotonView pv, int first_photon, const StepState *st, const uint32_t *input_queue,
+                int32_t *hit_triangle, float *hit_distance, DeviceCounters *counters)
 {
+    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    const uint32_t *retry_counter = &st->retry;
     __shared__ uint32_t s_lds[TRAV_LDS_WORDS(STACK_LDS, PROP_BLOCK)];
     if (*retry_counter == 0u) return;
     LaneCounters cnt = {0, 0, 0, 0};
@@ -920,11 +966,15 @@ k_raycast_retry(GeoView g, PhotonView pv, int first_photon, int nthreads, const 
 
 #define PHYS_BLOCK 512
 __global__ __launch_bounds__(PHYS_BLOCK) void
-k_physics(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue, uint32_t *output_queue,
+k_physics(GeoView g, PhotonView pv, int first_photon, const StepState *st, const uint32_t *input_queue, uint32_t *output_queue,
           const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base, int use_weights,
-          int scatter_first, int renorm)
+          int scatter_first)
 {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
+    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    // the grid is sized for an upper bound of the photon count: blocks stride over the queue
+    for (int block_base = blockIdx.x * PHYS_BLOCK; block_base < nthreads; block_base += gridDim.x * PHYS_BLOCK) {
+    int id = block_base + threadIdx.x;
     bool alive = false;
     uint32_t photon_id = 0;
     if (id < nthreads) {
@@ -967,8 +1017,9 @@ k_physics(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32
             alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
         }
     }
-    __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
     if (output_queue) block_queue_append<PHYS_BLOCK / WAVE>(output_queue, alive, photon_id, s_counts);
+    __syncthreads();        // s_counts is reused by the next round
+    }
 }
 
 // initial queue of GPUPhotons.propagate (chroma/gpu/photon.py:206-216): slot 0 unused counter,
@@ -976,7 +1027,7 @@ k_physics(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32
 __global__ void k_init_queue(uint32_t *queue, uint64_t n, uint32_t ncopies, uint32_t true_n)
 {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == 0) queue[0] = 0;
+    if (j == 0) queue[0] = (uint32_t)n + 1u;      // slot 0 = tail index, as after a step that queued all n
     if (j < n) {
         uint32_t copy = (uint32_t)(j % ncopies);
         uint32_t idx = (uint32_t)(j / ncopies);
@@ -1291,17 +1342,16 @@ static int launch_propagate(chroma_ctx *ctx, chroma_geometry *geom, PhotonView p
 }
 
 // one step for many photons: ray cast and physics as two launches
-static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, int nthreads, const uint32_t *in_q,
-                             uint32_t *out_q, chroma_rng rng, int use_weights, int scatter_first, bool mark_raycast_end = false,
-                             int renorm = 1)
+// One step as ray cast + retry pass + physics, all reading the photon count and the launch policy
+// from ctx->d_step (k_step_begin).  `n_upper` bounds the count and sizes the grids; `in_q`/`out_q`
+// are whole queues (slot 0 = tail).  With `ev` the three events bracket the ray cast and the step.
+static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, long long n_upper, const uint32_t *in_q,
+                             uint32_t *out_q, chroma_rng rng, int use_weights, int scatter_first, hipEvent_t *ev = nullptr)
 {
-    if (nthreads <= 0) return CHROMA_OK;
+    if (n_upper <= 0) return CHROMA_OK;
     uint32_t need = geom->stack_need;
     if (need > STACK_LDS + STACK_SCRATCH)
         return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
-    // persistent ray cast: enough waves to fill the chip a few times over, each pulling rays
-    // from the queue through ctx->d_words[4]; d_words[5] counts the rays left for the retry pass
-    HIP_TRY(hipMemsetAsync(ctx->d_words + 4, 0, 8, ctx->stream));
     const bool have_wide = geom->view.wnodes != nullptr;
     const bool coop = ctx->wide_walk == CHROMA_WALK_COOP && have_wide && geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
     const bool wide = !coop && ctx->wide_walk != CHROMA_WALK_REFERENCE && have_wide && geom->wide_stack_need <= WIDE_STACK + WIDE_SPILL;
@@ -1313,39 +1363,36 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipMalloc((void **)&ctx->coop_spill, (size_t)ctx->coop_waves * 8 * COOP_SPILL * sizeof(uint2)));
     }
-    // rays a wave takes from the queue per atomic: many for big batches (a hot word serves only
-    // ~88 atomics/us), one wave-load when every wave gets only a few rounds anyway
-    unsigned waves;
-    int chunk;
-    if (coop) {
-        waves = (unsigned)std::min<long long>(((long long)nthreads + 7) / 8, (long long)ctx->coop_waves);
-        chunk = ((long long)nthreads > 4ll * ctx->coop_chunk * ctx->coop_waves) ? ctx->coop_chunk : 8;
-    } else {
-        waves = (unsigned)std::min<long long>(((long long)nthreads + PROP_BLOCK - 1) / PROP_BLOCK,
-                                              (long long)(wide ? ctx->wide_waves : ctx->persistent_waves));
-        chunk = ((long long)nthreads > 4ll * ctx->ray_chunk * ctx->wide_waves) ? ctx->ray_chunk : PROP_BLOCK;
-    }
+    // persistent ray cast: enough waves to fill the chip, each pulling rays from the queue
+    unsigned waves = coop ? (unsigned)std::min<long long>((n_upper + 7) / 8, (long long)ctx->coop_waves)
+                          : (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK,
+                                                          (long long)(wide ? ctx->wide_waves : ctx->persistent_waves));
     dim3 grid(waves), block(PROP_BLOCK);
-    uint32_t *work = ctx->d_words + 4, *retry = ctx->d_words + 5;
+    StepState *st = ctx->d_step;
+    const uint32_t *q = in_q + 1;
+    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st, (uint32_t)(PROP_BLOCK * 16 * 8));
+    if (ev) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
 #define RAYCAST_LAUNCH(COUNT)                                                                                          \
     do {                                                                                                               \
         if (coop)                                                                                                      \
-            hipLaunchKernelGGL((k_raycast_coop<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q, \
-                               ctx->hit_triangle, ctx->hit_distance, work, retry, ctx->coop_spill, ctx->d_counters, renorm, chunk); \
+            hipLaunchKernelGGL((k_raycast_coop<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,          \
+                               ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
         else if (wide)                                                                                                 \
-            hipLaunchKernelGGL((k_raycast_wide<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q, \
-                               ctx->hit_triangle, ctx->hit_distance, work, retry, ctx->wide_spill, ctx->d_counters, renorm, chunk); \
+            hipLaunchKernelGGL((k_raycast_wide<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,          \
+                               ctx->hit_triangle, ctx->hit_distance, ctx->wide_spill, ctx->d_counters, ctx->ray_chunk); \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_raycast_persistent<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, nthreads, \
-                               in_q, ctx->hit_triangle, ctx->hit_distance, work, retry, ctx->d_counters, renorm);       \
-        if (mark_raycast_end) HIP_TRY(hipEventRecord(ctx->ev_mid, ctx->stream));                                        \
-        hipLaunchKernelGGL((k_raycast_retry<COUNT>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, nthreads, in_q, \
-                           ctx->hit_triangle, ctx->hit_distance, retry, ctx->d_counters, renorm);                       \
+            hipLaunchKernelGGL((k_raycast_persistent<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,    \
+                               ctx->hit_triangle, ctx->hit_distance, ctx->d_counters);                                 \
+        if (ev) HIP_TRY(hipEventRecord(ev[1], ctx->stream));                                                            \
+        hipLaunchKernelGGL((k_raycast_retry<COUNT>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, st, q,        \
+                           ctx->hit_triangle, ctx->hit_distance, ctx->d_counters);                                     \
     } while (0)
     if (ctx->counting) RAYCAST_LAUNCH(true); else RAYCAST_LAUNCH(false);
 #undef RAYCAST_LAUNCH
-    hipLaunchKernelGGL(k_physics, dim3((unsigned)((nthreads + PHYS_BLOCK - 1) / PHYS_BLOCK)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, 0, nthreads,
-                       in_q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first, renorm);
+    unsigned pblocks = (unsigned)std::min<long long>((n_upper + PHYS_BLOCK - 1) / PHYS_BLOCK, (long long)ctx->physics_blocks);
+    hipLaunchKernelGGL(k_physics, dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, 0, st,
+                       q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first);
+    if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
 }
@@ -1426,12 +1473,16 @@ int chroma_init(int device, chroma_ctx **out)
     HIP_TRY(hipMalloc((void **)&ctx->d_words, 16 * sizeof(uint32_t)));
     HIP_TRY(hipMemset(ctx->d_words, 0, 16 * sizeof(uint32_t)));
     HIP_TRY(hipHostMalloc((void **)&ctx->h_words, 16 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&ctx->d_step, sizeof(StepState)));
+    HIP_TRY(hipMemset(ctx->d_step, 0, sizeof(StepState)));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_step, sizeof(StepState), hipHostMallocDefault));
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         int per_cu = 20;                     // LDS-limited residency of k_raycast_persistent (8 KB per wave)
         if (const char *e = getenv("CHROMA_RAY_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));
         ctx->persistent_waves = prop.multiProcessorCount * per_cu;
+        ctx->physics_blocks = prop.multiProcessorCount * 8;
         int wide_per_cu = 14;                // LDS-limited residency of k_raycast_wide
         if (const char *e = getenv("CHROMA_WIDE_WAVES_PER_CU")) wide_per_cu = std::max(1, atoi(e));
         ctx->wide_waves = prop.multiProcessorCount * wide_per_cu;
@@ -1460,6 +1511,9 @@ int chroma_shutdown(chroma_ctx *ctx)
     if (ctx->queue_b) hipFree(ctx->queue_b);
     if (ctx->wide_spill) hipFree(ctx->wide_spill);
     if (ctx->coop_spill) hipFree(ctx->coop_spill);
+    if (ctx->d_step) hipFree(ctx->d_step);
+    if (ctx->h_step) hipHostFree(ctx->h_step);
+    for (hipEvent_t e : ctx->step_events) hipEventDestroy(e);
     if (ctx->hit_triangle) hipFree(ctx->hit_triangle);
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
     hipFree(ctx->d_counters);
@@ -1960,53 +2014,82 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
 
     double kernel_ms = 0.0, raycast_ms = 0.0;
     uint64_t launches = 0, raycast_launches = 0;
-    uint64_t n = nphotons;
-    int step = 0;
     // Launch policy of the reference (chroma/gpu/photon.py:225-252): one step per launch while many
     // photons are alive, and ONE launch for all remaining steps once fewer than 64*16*8 are left (or
     // with weights).  A launch re-normalises dir/pol when it loads a photon (propagate.cu:248,250), so
-    // the policy is part of the arithmetic.  Here that last launch is either the fused kernel, or
-    // (default without weights) a run of one-step launches that skip the re-normalisation after
-    // their first: same numbers, but every step gets the whole chip instead of < 128 waves.
-    bool in_tail = false;
-    while (step < max_steps) {
-        const bool few = n < (uint64_t)PROP_BLOCK * 16 * 8;
-        const bool fused = use_weights || (few && !ctx->split_tail);
-        int nsteps = fused ? (max_steps - step) : 1;
-        int renorm = 1;
-        if (!fused) {
-            if (in_tail) renorm = 0;
-            else if (few) in_tail = true;
-        }
-        if (time_kernels) HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-        if (!fused)
-            rc = launch_split_step(ctx, geom, pv, (int)n, in_q + 1, out_q, rng, use_weights, scatter_first, time_kernels != 0, renorm);
-        else
-            rc = launch_propagate(ctx, geom, pv, 0, (int)n, in_q + 1, out_q, rng, nsteps, use_weights, scatter_first);
-        if (rc) return rc;
-        if (renorm) launches++;          // launches in the reference's sense
-        if (time_kernels) {
-            HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
-            HIP_TRY(hipEventSynchronize(ctx->ev_stop));
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
-            kernel_ms += ms;
-            if (!fused) {
-                HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_mid));
-                raycast_ms += ms;
-                raycast_launches++;
+    // the policy is part of the arithmetic.  Without weights every step here is a ray cast + physics
+    // pair that gets the whole chip; a step that the reference would run inside its last launch skips
+    // the re-normalisation instead (same numbers).  The policy is evaluated ON THE DEVICE
+    // (k_step_begin), so the steps are enqueued back to back; the host looks at the survivor count
+    // only now and then, to stop early and to shrink the grids.
+    const bool device_steps = !use_weights && ctx->split_tail;
+    if (device_steps) {
+        HIP_TRY(hipMemsetAsync(ctx->d_step, 0, sizeof(StepState), ctx->stream));
+        const int nev = time_kernels ? 3 * max_steps : 0;
+        while ((int)ctx->step_events.size() < nev) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->step_events.push_back(e); }
+        long long n_upper = (long long)nphotons;
+        int step = 0, next_check = 1, steps_timed = 0;
+        bool done = false;
+        while (step < max_steps && !done) {
+            rc = launch_split_step(ctx, geom, pv, n_upper, in_q, out_q, rng, 0, step == 0 ? scatter_first : 0,
+                                   time_kernels ? ctx->step_events.data() + 3 * step : nullptr);
+            if (rc) return rc;
+            if (time_kernels) steps_timed = step + 1;
+            step++;
+            std::swap(in_q, out_q);
+            if (step == next_check && step < max_steps) {
+                // survivors = tail - 1 of what is now the input queue
+                HIP_TRY(hipMemcpyAsync(ctx->h_words + 1, in_q, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                n_upper = (long long)ctx->h_words[1] - 1;
+                if (n_upper <= 0) done = true;
+                next_check = (step < 8) ? step * 2 : step + 8;
             }
         }
-        step += nsteps;
-        scatter_first = 0;
-        if (step < max_steps) {
-            std::swap(in_q, out_q);
-            // survivors = tail - 1 (one 4-byte read per step, as photon.py:250)
-            HIP_TRY(hipMemcpyAsync(ctx->h_words + 1, in_q, 4, hipMemcpyDeviceToHost, ctx->stream));
-            hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, out_q, 1u);
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            n = (uint64_t)ctx->h_words[1] - 1;
-            if (n == 0) break;
+        HIP_TRY(hipMemcpyAsync(ctx->h_step, ctx->d_step, sizeof(StepState), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        launches = ((const StepState *)ctx->h_step)->launches;
+        for (int k = 0; k < steps_timed; k++) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[3 * k], ctx->step_events[3 * k + 2]));
+            kernel_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[3 * k], ctx->step_events[3 * k + 1]));
+            raycast_ms += ms;
+            raycast_launches++;
+        }
+    } else {
+        uint64_t n = nphotons;
+        int step = 0;
+        while (step < max_steps) {
+            const bool few = n < (uint64_t)PROP_BLOCK * 16 * 8;
+            int nsteps = (few || use_weights) ? (max_steps - step) : 1;
+            if (time_kernels) HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+            if (nsteps == 1) {
+                HIP_TRY(hipMemsetAsync(ctx->d_step, 0, sizeof(StepState), ctx->stream));      // not in the tail: re-normalise
+                rc = launch_split_step(ctx, geom, pv, (long long)n, in_q, out_q, rng, use_weights, scatter_first);
+            } else {
+                rc = launch_propagate(ctx, geom, pv, 0, (int)n, in_q + 1, out_q, rng, nsteps, use_weights, scatter_first);
+            }
+            if (rc) return rc;
+            launches++;
+            if (time_kernels) {
+                HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+                HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+                kernel_ms += ms;
+            }
+            step += nsteps;
+            scatter_first = 0;
+            if (step < max_steps) {
+                std::swap(in_q, out_q);
+                // survivors = tail - 1 (one 4-byte read per step, as photon.py:250)
+                HIP_TRY(hipMemcpyAsync(ctx->h_words + 1, in_q, 4, hipMemcpyDeviceToHost, ctx->stream));
+                hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, out_q, 1u);
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                n = (uint64_t)ctx->h_words[1] - 1;
+                if (n == 0) break;
+            }
         }
     }
     // abort warning word (photon.py:254-255)
