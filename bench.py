@@ -38,6 +38,9 @@ def log(*a):
         print('[bench]', *a, file=sys.stderr, flush=True)
 
 
+RAYCAST_KERNEL = {'reference': 'k_raycast_persistent', 'wide': 'k_raycast_wide'}.get(os.environ.get('CHROMA_WALK', ''), 'k_raycast_coop')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -187,8 +190,9 @@ def main():
     kernel_s = stats['kernel_ms'] / 1e3
     launches = max(1, stats['launches'])
     path_achieved = (bytes_per_photon * nphotons * args.steps) / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    # dominant kernel: the ray cast (k_raycast_persistent + its retry pass).  Algorithmic bytes per
-    # photon step: 16 B per node visited + 48 B per triangle tested + 36 B ray state read + 8 B hit written
+    # dominant kernel: the ray cast (k_raycast_coop; the retry pass after it is normally empty).
+    # Algorithmic bytes per photon step: 16 B per child entry fetched (a 128-B wide node = 8 entries)
+    # + 48 B per triangle tested + 36 B ray state read + 8 B hit written
     ray_s = stats['raycast_ms'] / 1e3
     ray_launches = max(1, stats['raycast_launches'])
     ray_bytes_per_step = 16.0 * nodes_ps + 48.0 * tris_ps + 36 + 8
@@ -240,7 +244,7 @@ def main():
                        'engine_seed': ENGINE_SEED, 'parallelism': 'photon shards x%d, geometry replicated' % world,
                        'steps_per_photon': steps_pp, 'nodes_per_step': nodes_ps, 'triangle_tests_per_step': tris_ps,
                        'geometry_build_s': t_build},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_raycast_persistent', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': RAYCAST_KERNEL, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': ray_bytes_total / ray_launches,
                          'algorithmic_bytes_per_photon_step': ray_bytes_per_step,

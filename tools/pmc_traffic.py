@@ -4,10 +4,11 @@ HBM bytes = 2 * FETCH_SIZE(KB) * 1024 + WRITE_SIZE(KB) * 1024.  The factor 2 on 
 correction of MI355X_MICROARCH.md (requests of 128 B tallied at 64 B), re-calibrated for THIS access pattern
 with tools/calib_fetch.hip: 268 M scattered 16-B reads report 64 B each while running at the 128-B-line rate of
 the streaming peak (6.3 TB/s), and a 4 GiB coalesced stream reports 2 GiB.  WRITE_SIZE is taken as is.
-usage: pmc_traffic.py FETCH_DIR WRITE_DIR key
+usage: pmc_traffic.py FETCH_DIR WRITE_DIR key [kernel-name-substring, default k_raycast_coop]
 """
 import csv, glob, json, os, sys
 fetch_dir, write_dir, key = sys.argv[1:4]
+kernel = sys.argv[4] if len(sys.argv) > 4 else 'k_raycast_coop'
 def total(d, counter, name):
     tot, n = 0.0, 0
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
@@ -19,9 +20,9 @@ out = {}
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'pmc_traffic.json')
 if os.path.exists(path):
     out = json.load(open(path))
-f, nf = total(fetch_dir, 'FETCH_SIZE', 'k_raycast_persistent')
-w, nw = total(write_dir, 'WRITE_SIZE', 'k_raycast_persistent')
-out[key] = {'kernel': 'k_raycast_persistent', 'launches': nf, 'fetch_size_kb_sum': f, 'write_size_kb_sum': w,
+f, nf = total(fetch_dir, 'FETCH_SIZE', kernel)
+w, nw = total(write_dir, 'WRITE_SIZE', kernel)
+out[key] = {'kernel': kernel, 'launches': nf, 'fetch_size_kb_sum': f, 'write_size_kb_sum': w,
             'hbm_bytes_per_launch': (2.0 * f + w) * 1024.0 / max(nf, 1),
             'correction': 'FETCH_SIZE x2 (gfx950, calibrated with tools/calib_fetch.hip), WRITE_SIZE x1'}
 json.dump(out, open(path, 'w'), indent=1)
