@@ -58,6 +58,7 @@ struct chroma_ctx {
     // (triangle, distance) per queue slot handed from k_raycast to k_physics
     int32_t *hit_triangle = nullptr;
     float *hit_distance = nullptr;
+    int32_t *last_hit_dev = nullptr;       // [capacity] last_hit_triangles as record indices (PhotonView::last_hit_dev)
     // small device scratch: [0..3] DeviceCounters, then misc words
     DeviceCounters *d_counters = nullptr;
     uint32_t *d_words = nullptr;        // 16 words
@@ -200,52 +201,6 @@ k_propagate(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint
 #define HIT_SKIP (-3)      // photon already terminal: untouched (propagate.cu:258)
 #define HIT_NAN  (-2)      // NaN guard fired (propagate.cu:270-273)
 
-template <int LDS_N, bool COUNT>
-__global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
-k_raycast(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint32_t *input_queue,
-          int32_t *hit_triangle, float *hit_distance, DeviceCounters *counters)
-{
-    __shared__ uint32_t s_lds[TRAV_LDS_WORDS(LDS_N, PROP_BLOCK)];
-    int id = blockIdx.x * PROP_BLOCK + threadIdx.x;
-    LaneCounters cnt = {0, 0, 0, 0};
-    int tri = HIT_SKIP;
-    float dist = 0.0f;
-    bool cast = false;
-    v3 position = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
-    int last_hit = -1;
-    if (id < nthreads) {
-        uint32_t photon_id = input_queue ? input_queue[first_photon + id] : (uint32_t)(first_photon + id);
-        if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
-            position = load3(pv.pos, photon_id);
-            direction = load3(pv.dir, photon_id);
-            direction = direction / norm(direction);
-            if (cm_isnan(direction.x * direction.y * direction.z * position.x * position.y * position.z)) {
-                tri = HIT_NAN;
-            } else {
-                cast = true;
-                last_hit = pv.last_hit_triangles[photon_id];
-                if (COUNT) cnt.steps++;
-            }
-        }
-    }
-    int found = intersect_mesh<LDS_N, PROP_BLOCK, COUNT>(g, position, direction, dist, last_hit, s_lds + threadIdx.x, cnt, cast);
-    if (cast) tri = found;
-    if (id < nthreads) {
-        hit_triangle[first_photon + id] = tri;
-        hit_distance[first_photon + id] = dist;
-    }
-    unsigned long long ov = wave_sum_u64(cnt.overflows);
-    if (COUNT) {
-        unsigned long long st = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
-        if (lane_id() == 0) {
-            atomicAdd(&counters->photon_steps, st);
-            atomicAdd(&counters->nodes_visited, nd);
-            atomicAdd(&counters->triangles_tested, tr);
-        }
-    }
-    if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
-}
-
 // ---- device-side step control ---------------------------------------------------------------------
 // chroma_propagate enqueues its steps without waiting for any of them: how many photons a step has
 // (the tail of its input queue), whether its launch re-normalises (the reference's launch policy,
@@ -339,8 +294,7 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, StepState *st, 
                             } else {
                                 if (COUNT) cnt.steps++;
                                 rf = ray_fast(g, noid, inv_dir);
-                                last_hit = pv.last_hit_triangles[photon_id];
-                                if (last_hit >= 0) last_hit = (int)g.tri_to_dev[last_hit];      // device index (leaf order)
+                                last_hit = pv.last_hit_dev[photon_id];
                                 triangle_index = -1;
                                 min_distance = -1.0f;
                                 sp = 0;
@@ -432,7 +386,7 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, StepState *st, 
 
         // ---- retire finished rays
         if (has_ray && !active) {
-            hit_triangle[slot] = (triangle_index >= 0) ? (int)g.dev_to_tri[triangle_index] : triangle_index;
+            hit_triangle[slot] = triangle_index;                 // record index, or a HIT_* code
             hit_distance[slot] = min_distance;
             if (triangle_index == HIT_RETRY) atomicAdd(retry_counter, 1u);
             has_ray = false;
@@ -546,8 +500,7 @@ k_raycast_wide(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                             } else {
                                 if (COUNT) cnt.steps++;
                                 rf = ray_fast(g, noid, inv_dir);
-                                last_hit = pv.last_hit_triangles[photon_id];
-                                if (last_hit >= 0) last_hit = (int)g.tri_to_dev[last_hit];
+                                last_hit = pv.last_hit_dev[photon_id];
                                 triangle_index = -1;
                                 min_distance = -1.0f;
                                 sp = 0;
@@ -652,7 +605,7 @@ k_raycast_wide(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
 
         // ---- retire finished rays
         if (has_ray && !active) {
-            hit_triangle[slot] = (triangle_index >= 0) ? (int)g.dev_to_tri[triangle_index] : triangle_index;
+            hit_triangle[slot] = triangle_index;                 // record index, or a HIT_* code
             hit_distance[slot] = min_distance;
             if (triangle_index == HIT_RETRY) atomicAdd(retry_counter, 1u);
             has_ray = false;
@@ -783,8 +736,7 @@ k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                         } else {
                             if (COUNT && j == 0) cnt.steps++;
                             rf = ray_fast(g, noid, inv_dir);
-                            last_hit = pv.last_hit_triangles[photon_id];
-                            if (last_hit >= 0) last_hit = (int)g.tri_to_dev[last_hit];
+                            last_hit = pv.last_hit_dev[photon_id];
                             triangle_index = -1;
                             min_distance = -1.0f;
                             sp = 0;
@@ -898,7 +850,7 @@ k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
         // ---- retire finished rays
         if (has_ray && !active) {
             if (j == 0) {
-                hit_triangle[slot] = (triangle_index >= 0) ? (int)g.dev_to_tri[triangle_index] : triangle_index;
+                hit_triangle[slot] = triangle_index;                 // record index, or a HIT_* code
                 hit_distance[slot] = min_distance;
                 if (triangle_index == HIT_RETRY) atomicAdd(retry_counter, 1u);
             }
@@ -940,13 +892,13 @@ k_raycast_retry(GeoView g, PhotonView pv, int first_photon, const StepState *st,
             position = load3(pv.pos, photon_id);
             direction = load3(pv.dir, photon_id);
             if (renorm) direction = direction / norm(direction);
-            last_hit = pv.last_hit_triangles[photon_id];
+            last_hit = pv.last_hit_dev[photon_id];
             cast = true;
             if (COUNT) cnt.steps++;
         }
         if (!__any(cast)) continue;
         float dist;
-        int found = intersect_mesh<STACK_LDS, PROP_BLOCK, COUNT>(g, position, direction, dist, last_hit, s_lds + threadIdx.x, cnt, cast);
+        int found = intersect_mesh_dev<STACK_LDS, PROP_BLOCK, COUNT>(g, position, direction, dist, last_hit, s_lds + threadIdx.x, cnt, cast);
         if (cast) {
             hit_triangle[slot] = found;
             hit_distance[slot] = dist;
@@ -1001,8 +953,10 @@ k_physics(GeoView g, PhotonView pv, int first_photon, const StepState *st, const
                 p.history |= CHROMA_NO_HIT | CHROMA_NAN_ABORT;
             } else {
                 State s;
-                apply_hit(s, p, g, tri, hit_distance[first_photon + id]);
+                apply_hit_dev(s, p, g, tri, hit_distance[first_photon + id]);
                 if (tri != -1) step_after_hit(p, s, rng, g, use_weights != 0, scatter_first);
+                // (a photon scattered or absorbed in the bulk forgets the triangle, photon.h:232,262,283)
+                pv.last_hit_dev[photon_id] = (p.last_hit_triangle < 0) ? -1 : tri;
             }
             pv.rng_counters[photon_id] = rng.counter;
             store3(pv.pos, photon_id, p.position);
@@ -1036,6 +990,16 @@ __global__ void k_init_queue(uint32_t *queue, uint64_t n, uint32_t ncopies, uint
 }
 
 __global__ void k_set_word(uint32_t *p, uint32_t v) { *p = v; }
+
+// last_hit_triangles (triangle ids, API array) -> record indices for the step kernels
+__global__ void k_last_hit_to_records(const int32_t *last_hit_triangles, const uint32_t *tri_to_dev, int32_t *last_hit_dev,
+                                      uint64_t n, uint32_t ntriangles)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t t = last_hit_triangles[i];
+    last_hit_dev[i] = (t >= 0 && (uint32_t)t < ntriangles) ? (int32_t)tri_to_dev[t] : -1;
+}
 
 // OR of (flags & mask) over all photons -> one word (abort warning, photon.py:254)
 __global__ void k_flags_or(const uint32_t *flags, uint64_t n, uint32_t mask, uint32_t *out)
@@ -1301,6 +1265,7 @@ static PhotonView to_view(const chroma_photon_arrays *a)
     PhotonView v;
     v.pos = a->pos; v.dir = a->dir; v.pol = a->pol; v.wavelengths = a->wavelengths; v.t = a->t;
     v.flags = a->flags; v.last_hit_triangles = a->last_hit_triangles; v.weights = a->weights;
+    v.last_hit_dev = nullptr;
     v.evidx = a->evidx; v.rng_counters = a->rng_counters;
     return v;
 }
@@ -1516,6 +1481,7 @@ int chroma_shutdown(chroma_ctx *ctx)
     for (hipEvent_t e : ctx->step_events) hipEventDestroy(e);
     if (ctx->hit_triangle) hipFree(ctx->hit_triangle);
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
+    if (ctx->last_hit_dev) hipFree(ctx->last_hit_dev);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_words);
     hipHostFree(ctx->h_words);
@@ -1710,8 +1676,8 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
                     const float *vv = d->vertices + 3 * (size_t)d->triangles[3 * t + c];
                     r[4 * c] = vv[0]; r[4 * c + 1] = vv[1]; r[4 * c + 2] = vv[2];
                 }
-                uint32_t code = d->material_codes[t], sid = d->solid_id_map ? d->solid_id_map[t] : 0u, rank = wt.rank[t];
-                memcpy(&r[3], &code, 4); memcpy(&r[7], &sid, 4); memcpy(&r[11], &rank, 4);
+                uint32_t code = d->material_codes[t], tid = (uint32_t)t, rank = wt.rank[t];
+                memcpy(&r[3], &code, 4); memcpy(&r[7], &tid, 4); memcpy(&r[11], &rank, 4);
             }
             e = hipMemcpy((char *)dtri + t0 * 48, stage.data(), (t1 - t0) * 48, hipMemcpyHostToDevice);
             if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "triangle upload: %s", hipGetErrorString(e)); }
@@ -1951,13 +1917,15 @@ static int ensure_queues(chroma_ctx *ctx, size_t n)
     if (ctx->queue_b) hipFree(ctx->queue_b);
     if (ctx->hit_triangle) hipFree(ctx->hit_triangle);
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
+    if (ctx->last_hit_dev) hipFree(ctx->last_hit_dev);
     ctx->queue_a = ctx->queue_b = nullptr;
-    ctx->hit_triangle = nullptr; ctx->hit_distance = nullptr;
+    ctx->hit_triangle = nullptr; ctx->hit_distance = nullptr; ctx->last_hit_dev = nullptr;
     ctx->queue_capacity = 0;
     HIP_TRY(hipMalloc((void **)&ctx->queue_a, (n + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->queue_b, (n + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->hit_triangle, (n + 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->hit_distance, (n + 1) * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&ctx->last_hit_dev, (n + 1) * sizeof(int32_t)));
     ctx->queue_capacity = n + 1;
     return CHROMA_OK;
 }
@@ -2005,6 +1973,10 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     HIP_TRY(hipSetDevice(ctx->device));
     rc = ensure_queues(ctx, nphotons); if (rc) return rc;
     PhotonView pv = to_view(photons);
+    pv.last_hit_dev = ctx->last_hit_dev;
+    hipLaunchKernelGGL(k_last_hit_to_records, dim3((unsigned)((nphotons + 255) / 256)), dim3(256), 0, ctx->stream,
+                       photons->last_hit_triangles, geom->view.tri_to_dev, ctx->last_hit_dev, (uint64_t)nphotons,
+                       geom->view.ntriangles);
     uint32_t *in_q = ctx->queue_a, *out_q = ctx->queue_b;
 
     hipLaunchKernelGGL(k_init_queue, dim3((unsigned)((nphotons + 255) / 256)), dim3(256), 0, ctx->stream, in_q,

@@ -40,7 +40,7 @@ __device__ inline void store3(float *p, size_t i, v3 v) { p[3 * i] = v.x; p[3 * 
 //   wnodes  uint4[nwide][8]          128 B wide node = one L2 line: eight child entries in the node
 //                                    format above, w = child wide node | 0x80000000+device triangle
 //                                    | 0xFFFFFFFF (empty); derived from `nodes` (csrc/wide_build.cpp)
-//   tri     float4[nrecords][3]      48 B record: v0.xyz|material_code, v1.xyz|solid_id, v2.xyz|rank
+//   tri     float4[nrecords][3]      48 B record: v0.xyz|material_code, v1.xyz|triangle id, v2.xyz|rank
 //                                    (one aligned 48-B gather instead of the reference's
 //                                     12-B index fetch + three 12-B vertex gathers).  `rank` is the
 //                                    triangle's position in the reference's test order (tie-break of
@@ -80,6 +80,10 @@ struct GeoView {
 struct PhotonView {   // device pointers of chroma_photon_arrays
     float *pos, *dir, *pol, *wavelengths, *t;
     uint32_t *flags; int32_t *last_hit_triangles; float *weights; uint32_t *evidx; uint32_t *rng_counters;
+    // internal to chroma_propagate: last_hit_triangles as triangle RECORD indices, kept beside the
+    // API array so that no step has to translate through tri_to_dev / dev_to_tri (three 128-B lines
+    // per photon step for 12 bytes)
+    int32_t *last_hit_dev;
 };
 
 struct DeviceCounters {   // accumulated with one atomic per wave

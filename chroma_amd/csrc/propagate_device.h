@@ -295,6 +295,22 @@ __device__ inline int intersect_mesh(const GeoView &g, v3 origin, v3 direction, 
     return (found >= 0) ? (int)g.dev_to_tri[found] : found;
 }
 
+// the same on triangle RECORD indices in and out (per-step kernels)
+template <int LDS_N, int BLOCK, bool COUNT>
+__device__ inline int intersect_mesh_dev(const GeoView &g, v3 origin, v3 direction, float &min_distance,
+                                         int last_hit_dev, uint32_t *lds, LaneCounters &cnt, bool lane_on = true)
+{
+    const v3 noid = (-origin) / direction;
+    const v3 inv_dir = 1.0f / direction;
+    bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                    cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+    if (__any(lane_on && !moderate))
+        return intersect_mesh_walk<LDS_N, BLOCK, COUNT, false>(g, origin, direction, noid, inv_dir, min_distance,
+                                                               last_hit_dev, lds, cnt, lane_on);
+    return intersect_mesh_walk<LDS_N, BLOCK, COUNT, true>(g, origin, direction, noid, inv_dir, min_distance,
+                                                          last_hit_dev, lds, cnt, lane_on);
+}
+
 // ---- random.h / interpolate.h -----------------------------------------------------------------
 __device__ inline float rng_u(cm_rng &r) { return cm_rng_uniform(&r); }
 __device__ inline float uniform(cm_rng &r, float low, float high) { return low + rng_u(r) * (high - low); }   // random.h:9-13
@@ -350,17 +366,11 @@ __device__ inline float get_theta(v3 a, v3 b)                                   
 
 // fill_state (photon.h:83-135), the part after the ray cast.  The triangle record already holds
 // the three vertices and the material code, so the second triangle fetch of the reference is one
-// 48-B read (an L2 hit right after the cast).
-__device__ inline void apply_hit(State &s, Photon &p, const GeoView &g, int triangle, float distance)
+// 48-B read (an L2 hit right after the cast).  `record` is the index of the triangle's record.
+__device__ inline void apply_hit_record(State &s, Photon &p, const GeoView &g, size_t record, float distance,
+                                        float4 a, float4 b, float4 c)
 {
-    p.last_hit_triangle = triangle;
     s.distance_to_boundary = distance;
-    if (triangle == -1) {
-        p.history |= CHROMA_NO_HIT;
-        return;
-    }
-    const float4 *t = g.tri + 3 * (size_t)g.tri_to_dev[triangle];
-    float4 a = t[0], b = t[1], c = t[2];
     v3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(b.x, b.y, b.z), v2 = mk3(c.x, c.y, c.z);
     uint32_t material_code = __float_as_uint(a.w);
 
@@ -386,6 +396,33 @@ __device__ inline void apply_hit(State &s, Photon &p, const GeoView &g, int tria
     s.absorption_length = interp_property(g, p.wavelength, row(g.mat_absorption_length, g, material1));
     s.scattering_length = interp_property(g, p.wavelength, row(g.mat_scattering_length, g, material1));
     s.material1 = material1;
+}
+// by triangle id (fused kernel)
+__device__ inline void apply_hit(State &s, Photon &p, const GeoView &g, int triangle, float distance)
+{
+    p.last_hit_triangle = triangle;
+    s.distance_to_boundary = distance;
+    if (triangle == -1) {
+        p.history |= CHROMA_NO_HIT;
+        return;
+    }
+    size_t record = g.tri_to_dev[triangle];
+    const float4 *t = g.tri + 3 * record;
+    apply_hit_record(s, p, g, record, distance, t[0], t[1], t[2]);
+}
+// by record index (what the per-step ray cast hands over); the record names its triangle
+__device__ inline void apply_hit_dev(State &s, Photon &p, const GeoView &g, int record, float distance)
+{
+    s.distance_to_boundary = distance;
+    if (record == -1) {
+        p.last_hit_triangle = -1;
+        p.history |= CHROMA_NO_HIT;
+        return;
+    }
+    const float4 *t = g.tri + 3 * (size_t)record;
+    float4 a = t[0], b = t[1], c = t[2];
+    p.last_hit_triangle = (int)__float_as_uint(b.w);
+    apply_hit_record(s, p, g, (size_t)record, distance, a, b, c);
 }
 
 
