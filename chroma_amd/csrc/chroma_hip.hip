@@ -74,6 +74,7 @@ struct chroma_ctx {
     int coop_waves = 256 * 32;             // grid of k_raycast_coop (2 KB of LDS per wave: wave slots limit residency)
     uint2 *coop_spill = nullptr;           // [coop_waves][8][COOP_SPILL]
     int ray_chunk = 256, coop_chunk = 64;  // rays a persistent wave takes from the queue per atomic (big batches)
+    int fused_tail = 1;                    // 0 (CHROMA_TAIL=split): the last photons also take one launch set per step
     int split_tail = 1;                    // 0 (CHROMA_TAIL=fused): the last launch of chroma_propagate is the fused kernel
     int wide_walk = 2;                     // CHROMA_WALK_*: 0 reference tree, 1 wide tree one lane per ray, 2 wide tree 8 lanes per ray
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
@@ -664,8 +665,11 @@ __device__ inline uint32_t group8_min_u32(uint32_t v)
     return v;
 }
 
+#ifndef COOP_WAVES_PER_EU
+#define COOP_WAVES_PER_EU 7
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(PROP_BLOCK) void
+__global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(COOP_WAVES_PER_EU, COOP_WAVES_PER_EU))) void
 k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
                int32_t *hit_triangle, float *hit_distance, uint2 *spill_base, DeviceCounters *counters, int big_chunk)
 {
@@ -862,6 +866,241 @@ k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
         unsigned long long st = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
         if (lane == 0) {
             atomicAdd(&counters->photon_steps, st);
+            atomicAdd(&counters->nodes_visited, nd);
+            atomicAdd(&counters->triangles_tested, tr);
+        }
+    }
+}
+
+// ---- fused tail: all remaining steps of the last few photons, eight lanes per photon ---------------
+// Once fewer than 64*16*8 photons are alive the reference finishes them in ONE launch
+// (chroma/gpu/photon.py:227-230).  Per-step launches are a poor fit for that tail -- a few thousand
+// rays, each a chain of ~30 dependent fetches, ~70 steps deep -- so it gets its own kernel: a group of
+// 8 lanes owns one photon for all its remaining steps, casts its rays cooperatively (coop_cast: the
+// walk of k_raycast_coop without the refill) and runs the physics redundantly in its 8 lanes (same
+// inputs, same arithmetic, so the lanes stay identical; lane 0 of the group stores).  No launch or
+// queue round trip between steps: the tail takes as long as its longest photon, not 70 launches.
+// Rays the wide walk cannot take go through the general walk on the group's first lane.
+template <bool COUNT>
+__device__ inline int coop_cast(const GeoView &g, v3 origin, v3 direction, int last_hit, bool on, float &min_distance,
+                                uint32_t *stack_n, float *stack_t, uint32_t *pending, uint2 *spill,
+                                unsigned j, unsigned gshift, uint32_t below, LaneCounters &cnt)
+{
+    const float inf = cm_inff();
+    int triangle_index = -1;
+    uint32_t best_rank = 0;
+    min_distance = -1.0f;
+    uint32_t cur = WIDE_NONE;
+    int sp = 0, npend = 0;
+    bool active = false;
+    RayFast rf;
+    rf.a = rf.blo = rf.bhi = mk3(0.f, 0.f, 0.f);
+    if (on) {
+        v3 noid = (-origin) / direction;
+        v3 inv_dir = 1.0f / direction;
+        bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                        cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+        if (!moderate) {
+            triangle_index = HIT_RETRY;
+        } else {
+            rf = ray_fast(g, noid, inv_dir);
+            cur = 0;
+            active = true;
+        }
+    }
+    while (__any(active || npend > 0)) {
+        // node phase
+        while (__any(active) && !__any(npend >= 8)) {
+            if (active && cur == WIDE_NONE) {
+                while (sp > 0) {
+                    sp--;
+                    uint32_t n; float t;
+                    if (sp < COOP_STACK) { n = stack_n[sp]; t = stack_t[sp]; }
+                    else { uint2 se = spill[sp - COOP_STACK]; n = se.x; t = __uint_as_float(se.y); }
+                    if (min_distance < 0.0f || !(t > min_distance)) { cur = n; break; }
+                }
+                if (cur == WIDE_NONE) active = false;
+            }
+            if (active) {
+                const uint4 e = g.wnodes[8 * (size_t)cur + j];
+                if (COUNT && j == 0) cnt.nodes += 8;
+                const float t = box_tmin_fast(rf, e);
+                const uint32_t w = e.w;
+                const bool pass = (w != WIDE_NONE) && node_passes(t, min_distance);
+                const bool isleaf = (w & 0x80000000u) != 0u;
+                const bool leaf = pass && isleaf && (int)(w & 0x7FFFFFFFu) != last_hit;
+                const bool inner = pass && !isleaf;
+                const uint32_t gl = (uint32_t)(__ballot(leaf) >> gshift) & 0xFFu;
+                const uint32_t gi = (uint32_t)(__ballot(inner) >> gshift) & 0xFFu;
+                if (leaf) pending[npend + __popc(gl & below)] = w & 0x7FFFFFFFu;
+                npend += __popc(gl);
+                cur = WIDE_NONE;
+                if (gi) {
+                    const float tm = group8_min(inner ? t : inf);
+                    const uint32_t gn = (uint32_t)(__ballot(inner && t == tm) >> gshift) & 0xFFu;
+                    const uint32_t nj = (uint32_t)__ffs((int)gn) - 1u;
+                    const uint32_t others = gi & ~(1u << nj);
+                    if (inner && j != nj) {
+                        int pos = sp + __popc(others & below);
+                        if (pos < COOP_STACK) { stack_n[pos] = w; stack_t[pos] = t; }
+                        else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(w, __float_as_uint(t));
+                    }
+                    sp += __popc(others);
+                    cur = (uint32_t)__shfl((int)w, (int)(gshift + nj));
+                    if (sp > COOP_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
+                        triangle_index = HIT_RETRY;
+                        active = false; npend = 0; cur = WIDE_NONE; sp = 0;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // leaf phase
+        while (__any(npend > 0)) {
+            if (npend > 0) {
+                const int take = min(npend, 8);
+                bool hit = false;
+                float distance = inf;
+                uint32_t tri = 0, rank = 0xFFFFFFFFu;
+                if ((int)j < take) {
+                    tri = pending[j];
+                    if (COUNT) cnt.tris++;
+                    const float4 *tp = g.tri + 3 * (size_t)tri;
+                    float4 a = tp[0], b = tp[1], c = tp[2];
+                    hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
+                    rank = __float_as_uint(c.w);
+                }
+                const float dm = group8_min(hit ? distance : inf);
+                if (dm < inf) {
+                    const bool cand = hit && distance == dm;
+                    const uint32_t rm = group8_min_u32(cand ? rank : 0xFFFFFFFFu);
+                    const uint32_t gw = (uint32_t)(__ballot(cand && rank == rm) >> gshift) & 0xFFu;
+                    const uint32_t wj = (uint32_t)__ffs((int)gw) - 1u;
+                    const int wtri = __shfl((int)tri, (int)(gshift + wj));
+                    if (triangle_index == -1 || dm < min_distance || (dm == min_distance && rm < best_rank)) {
+                        triangle_index = wtri;
+                        min_distance = dm;
+                        best_rank = rm;
+                    }
+                }
+                if (npend > 8) {
+                    uint32_t mv = pending[j + 8];
+                    if ((int)j + 8 < npend) pending[j] = mv;
+                }
+                npend -= take;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return triangle_index;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK) void
+k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input_queue, uint32_t *output_queue,
+            uint64_t seed, uint64_t id_base, int max_steps, int scatter_first, uint2 *spill_base, DeviceCounters *counters)
+{
+    __shared__ uint32_t s_coop[8 * COOP_STRIDE];
+    __shared__ uint32_t s_walk[TRAV_LDS_WORDS(STACK_LDS, PROP_BLOCK)];
+    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    if ((long long)blockIdx.x * 8 >= nthreads) return;
+    const unsigned lane = lane_id();
+    const unsigned j = lane & 7u, gshift = lane & ~7u, grp = lane >> 3;
+    const uint32_t below = (1u << j) - 1u;
+    uint32_t *stack_n = s_coop + grp * COOP_STRIDE;
+    float *stack_t = (float *)(stack_n + COOP_STACK);
+    uint32_t *pending = stack_n + 2 * COOP_STACK;
+    uint2 *spill = spill_base + ((size_t)blockIdx.x * 8 + grp) * COOP_SPILL;
+    LaneCounters cnt = {0, 0, 0, 0};
+
+    const int id = (int)blockIdx.x * 8 + (int)grp;          // one photon per group
+    bool loaded = false;
+    uint32_t photon_id = 0;
+    int last_hit_dev = -1;
+    Photon p;
+    cm_rng rng;
+    State s;
+    if (id < nthreads) {
+        photon_id = input_queue[id];
+        p.position = load3(pv.pos, photon_id);
+        p.direction = load3(pv.dir, photon_id);
+        p.polarization = load3(pv.pol, photon_id);
+        if (renorm) {
+            p.direction = p.direction / norm(p.direction);
+            p.polarization = p.polarization / norm(p.polarization);
+        }
+        p.wavelength = pv.wavelengths[photon_id];
+        p.time = pv.t[photon_id];
+        p.last_hit_triangle = pv.last_hit_triangles[photon_id];
+        last_hit_dev = pv.last_hit_dev[photon_id];
+        p.history = pv.flags[photon_id];
+        p.weight = pv.weights[photon_id];
+        p.evidx = pv.evidx[photon_id];
+        if (!(p.history & CHROMA_TERMINAL_MASK)) {
+            loaded = true;
+            cm_rng_init(&rng, seed, id_base + photon_id, pv.rng_counters[photon_id]);
+        }
+    }
+
+    bool live = loaded;
+    int steps = 0;
+    while (__any(live && steps < max_steps)) {
+        bool stepping = live && steps < max_steps;
+        if (stepping) {
+            steps++;
+            if (cm_isnan(p.direction.x * p.direction.y * p.direction.z * p.position.x * p.position.y * p.position.z)) {
+                p.history |= CHROMA_NO_HIT | CHROMA_NAN_ABORT;
+                live = false;
+                stepping = false;
+            } else if (COUNT && j == 0) cnt.steps++;
+        }
+        float distance;
+        int record = coop_cast<COUNT>(g, p.position, p.direction, last_hit_dev, stepping, distance, stack_n, stack_t, pending,
+                                      spill, j, gshift, below, cnt);
+        // the general walk for the rays the wide walk cannot take (first lane of the group, then shared)
+        bool general = stepping && record == HIT_RETRY;
+        if (__any(general)) {
+            float d2 = 0.0f;
+            int r2 = intersect_mesh_dev<STACK_LDS, PROP_BLOCK, COUNT>(g, p.position, p.direction, d2, last_hit_dev,
+                                                                       s_walk + threadIdx.x, cnt, general && j == 0);
+            r2 = __shfl(r2, (int)gshift);
+            d2 = __shfl(d2, (int)gshift);
+            if (general) { record = r2; distance = d2; }
+        }
+        if (stepping) {
+            apply_hit_dev(s, p, g, record, distance);
+            if (record == -1) {
+                live = false;
+                last_hit_dev = -1;
+            } else {
+                live = step_after_hit(p, s, rng, g, false, scatter_first);
+                scatter_first = 0;
+                last_hit_dev = (p.last_hit_triangle < 0) ? -1 : record;
+            }
+        }
+    }
+
+    bool alive = false;
+    if (loaded && j == 0) {
+        pv.rng_counters[photon_id] = rng.counter;
+        store3(pv.pos, photon_id, p.position);
+        store3(pv.dir, photon_id, p.direction);
+        store3(pv.pol, photon_id, p.polarization);
+        pv.wavelengths[photon_id] = p.wavelength;
+        pv.t[photon_id] = p.time;
+        pv.flags[photon_id] = p.history;
+        pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
+        pv.last_hit_dev[photon_id] = last_hit_dev;
+        pv.weights[photon_id] = p.weight;
+        pv.evidx[photon_id] = p.evidx;
+        alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
+    }
+    if (output_queue) wave_queue_append(output_queue, alive, photon_id);
+
+    if (COUNT) {
+        unsigned long long sts = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        if (lane == 0) {
+            atomicAdd(&counters->photon_steps, sts);
             atomicAdd(&counters->nodes_visited, nd);
             atomicAdd(&counters->triangles_tested, tr);
         }
@@ -1362,6 +1601,35 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     return CHROMA_OK;
 }
 
+// All remaining steps of the last photons in one launch (k_tail_coop).  Returns CHROMA_OK and sets
+// *done when the geometry has a wide tree the kernel can walk; otherwise leaves *done false.
+static int launch_tail(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, long long n_upper, const uint32_t *in_q,
+                       uint32_t *out_q, chroma_rng rng, int nsteps, int scatter_first, hipEvent_t *ev, bool *done)
+{
+    *done = false;
+    if (!geom->view.wnodes || geom->wide_stack_need > COOP_STACK + COOP_SPILL || geom->stack_need > STACK_LDS + STACK_SCRATCH)
+        return CHROMA_OK;
+    if (!ctx->coop_spill) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, (size_t)ctx->coop_waves * 8 * COOP_SPILL * sizeof(uint2)));
+    }
+    unsigned waves = (unsigned)std::min<long long>((n_upper + 7) / 8, (long long)ctx->coop_waves);
+    if ((long long)waves * 8 < n_upper) return CHROMA_OK;          // (cannot happen below 8192 photons)
+    StepState *st = ctx->d_step;
+    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st, (uint32_t)(PROP_BLOCK * 16 * 8));
+    if (ev) { HIP_TRY(hipEventRecord(ev[0], ctx->stream)); HIP_TRY(hipEventRecord(ev[1], ctx->stream)); }
+    if (ctx->counting)
+        hipLaunchKernelGGL((k_tail_coop<true>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, in_q + 1, out_q,
+                           rng.seed, rng.photon_id_base, nsteps, scatter_first, ctx->coop_spill, ctx->d_counters);
+    else
+        hipLaunchKernelGGL((k_tail_coop<false>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, in_q + 1, out_q,
+                           rng.seed, rng.photon_id_base, nsteps, scatter_first, ctx->coop_spill, ctx->d_counters);
+    if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+    HIP_TRY(hipGetLastError());
+    *done = true;
+    return CHROMA_OK;
+}
+
 template <class T>
 static int upload(chroma_geometry *g, const T *host, size_t count, const T **dev_out)
 {
@@ -1451,14 +1719,17 @@ int chroma_init(int device, chroma_ctx **out)
         int wide_per_cu = 14;                // LDS-limited residency of k_raycast_wide
         if (const char *e = getenv("CHROMA_WIDE_WAVES_PER_CU")) wide_per_cu = std::max(1, atoi(e));
         ctx->wide_waves = prop.multiProcessorCount * wide_per_cu;
-        int coop_per_cu = 24;                // 74 VGPRs: 6 waves per SIMD
+        int coop_per_cu = 28;                // 71 VGPRs (amdgpu_waves_per_eu 7): 7 waves per SIMD
         if (const char *e = getenv("CHROMA_COOP_WAVES_PER_CU")) coop_per_cu = std::max(1, atoi(e));
         ctx->coop_waves = prop.multiProcessorCount * coop_per_cu;
         if (const char *e = getenv("CHROMA_WALK"))
             ctx->wide_walk = !strcmp(e, "reference") ? CHROMA_WALK_REFERENCE : !strcmp(e, "wide") ? CHROMA_WALK_WIDE : CHROMA_WALK_COOP;
         if (const char *e = getenv("CHROMA_RAY_CHUNK")) ctx->ray_chunk = std::max(64, atoi(e));
         if (const char *e = getenv("CHROMA_COOP_CHUNK")) ctx->coop_chunk = std::max(8, atoi(e));
-        if (const char *e = getenv("CHROMA_TAIL")) ctx->split_tail = (strcmp(e, "fused") != 0);
+        if (const char *e = getenv("CHROMA_TAIL")) {      // coop (default) | split | fused (the lane-per-photon k_propagate)
+            ctx->split_tail = (strcmp(e, "fused") != 0);
+            ctx->fused_tail = (strcmp(e, "split") != 0 && strcmp(e, "fused") != 0);
+        }
     }
     HIP_TRY(hipEventCreate(&ctx->ev_start));
     HIP_TRY(hipEventCreate(&ctx->ev_stop));
@@ -2002,7 +2273,22 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         long long n_upper = (long long)nphotons;
         int step = 0, next_check = 1, steps_timed = 0;
         bool done = false;
+        const long long few = (long long)PROP_BLOCK * 16 * 8;
+        const bool fused_tail = ctx->fused_tail && ctx->wide_walk == CHROMA_WALK_COOP;    // (the cross-check walks keep per-step launches)
+        int tail_step = -1;                  // the step at which the fused tail was launched
         while (step < max_steps && !done) {
+            if (fused_tail && n_upper < few) {
+                // the reference's last launch: all remaining steps at once, 8 lanes per photon
+                bool launched = false;
+                rc = launch_tail(ctx, geom, pv, n_upper, in_q, out_q, rng, max_steps - step, step == 0 ? scatter_first : 0,
+                                 time_kernels ? ctx->step_events.data() + 3 * step : nullptr, &launched);
+                if (rc) return rc;
+                if (launched) {
+                    if (time_kernels) { tail_step = step; steps_timed = step + 1; }
+                    step = max_steps;
+                    break;
+                }
+            }
             rc = launch_split_step(ctx, geom, pv, n_upper, in_q, out_q, rng, 0, step == 0 ? scatter_first : 0,
                                    time_kernels ? ctx->step_events.data() + 3 * step : nullptr);
             if (rc) return rc;
@@ -2015,7 +2301,8 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                 HIP_TRY(hipStreamSynchronize(ctx->stream));
                 n_upper = (long long)ctx->h_words[1] - 1;
                 if (n_upper <= 0) done = true;
-                next_check = (step < 8) ? step * 2 : step + 8;
+                // look every step once the tail is near, so that it starts when the reference's does
+                next_check = (fused_tail && n_upper < 16 * few) ? step + 1 : (step < 8) ? step * 2 : step + 8;
             }
         }
         HIP_TRY(hipMemcpyAsync(ctx->h_step, ctx->d_step, sizeof(StepState), hipMemcpyDeviceToHost, ctx->stream));
@@ -2025,6 +2312,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[3 * k], ctx->step_events[3 * k + 2]));
             kernel_ms += ms;
+            if (k == tail_step) continue;             // the fused tail is not a ray-cast launch
             HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[3 * k], ctx->step_events[3 * k + 1]));
             raycast_ms += ms;
             raycast_launches++;
