@@ -1182,13 +1182,16 @@ k_physics(GeoView g, PhotonView pv, int first_photon, const StepState *st, const
             }
             p.wavelength = pv.wavelengths[photon_id];
             p.time = pv.t[photon_id];
-            p.last_hit_triangle = pv.last_hit_triangles[photon_id];
+            p.last_hit_triangle = -1;                // (set by apply_hit_dev)
             p.history = pv.flags[photon_id];
-            p.weight = pv.weights[photon_id];
-            p.evidx = pv.evidx[photon_id];
+            // evidx never changes; the weight only with weights on or a forced first scatter (photon.h:480-505)
+            const bool weight_live = use_weights || scatter_first;
+            p.weight = weight_live ? pv.weights[photon_id] : 1.0f;
+            p.evidx = 0;
             cm_rng rng;
             cm_rng_init(&rng, seed, id_base + photon_id, pv.rng_counters[photon_id]);
             if (tri == HIT_NAN) {
+                p.last_hit_triangle = pv.last_hit_triangles[photon_id];      // untouched (propagate.cu:270-273)
                 p.history |= CHROMA_NO_HIT | CHROMA_NAN_ABORT;
             } else {
                 State s;
@@ -1205,8 +1208,7 @@ k_physics(GeoView g, PhotonView pv, int first_photon, const StepState *st, const
             pv.t[photon_id] = p.time;
             pv.flags[photon_id] = p.history;
             pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
-            pv.weights[photon_id] = p.weight;
-            pv.evidx[photon_id] = p.evidx;
+            if (weight_live) pv.weights[photon_id] = p.weight;
             alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
         }
     }
