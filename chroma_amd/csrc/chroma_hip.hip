@@ -59,6 +59,7 @@ struct chroma_ctx {
     int32_t *hit_triangle = nullptr;
     float *hit_distance = nullptr;
     int32_t *last_hit_dev = nullptr;       // [capacity] last_hit_triangles as record indices (PhotonView::last_hit_dev)
+    uint32_t *retry_list = nullptr;        // [capacity] queue slots handed to k_raycast_retry
     // small device scratch: [0..3] DeviceCounters, then misc words
     DeviceCounters *d_counters = nullptr;
     uint32_t *d_words = nullptr;        // 16 words
@@ -241,7 +242,7 @@ __global__ void k_step_begin(const uint32_t *in_queue, uint32_t *out_queue, Step
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
 k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
-                     int32_t *hit_triangle, float *hit_distance, DeviceCounters *counters)
+                     int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, DeviceCounters *counters)
 {
     const int nthreads = (int)st->n, renorm = (int)st->renorm;
     if ((long long)blockIdx.x * PROP_BLOCK >= nthreads) return;
@@ -293,7 +294,6 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, StepState *st, 
                             if (!moderate) {
                                 result = HIT_RETRY;
                             } else {
-                                if (COUNT) cnt.steps++;
                                 rf = ray_fast(g, noid, inv_dir);
                                 last_hit = pv.last_hit_dev[photon_id];
                                 triangle_index = -1;
@@ -316,7 +316,7 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, StepState *st, 
                     if (!has_ray) {                      // nothing to cast for this slot
                         hit_triangle[slot] = result;
                         hit_distance[slot] = 0.0f;
-                        if (result == HIT_RETRY) atomicAdd(retry_counter, 1u);
+                        if (result == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
                     }
                 }
             }
@@ -389,7 +389,7 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, StepState *st, 
         if (has_ray && !active) {
             hit_triangle[slot] = triangle_index;                 // record index, or a HIT_* code
             hit_distance[slot] = min_distance;
-            if (triangle_index == HIT_RETRY) atomicAdd(retry_counter, 1u);
+            if (triangle_index == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
             has_ray = false;
         }
     }
@@ -430,7 +430,8 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, StepState *st, 
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
 k_raycast_wide(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
-               int32_t *hit_triangle, float *hit_distance, uint2 *spill_base, DeviceCounters *counters, int big_chunk)
+               int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint2 *spill_base, DeviceCounters *counters,
+               int big_chunk)
 {
     const int nthreads = (int)st->n, renorm = (int)st->renorm;
     if ((long long)blockIdx.x * PROP_BLOCK >= nthreads) return;
@@ -499,7 +500,6 @@ k_raycast_wide(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                             if (!moderate) {
                                 result = HIT_RETRY;
                             } else {
-                                if (COUNT) cnt.steps++;
                                 rf = ray_fast(g, noid, inv_dir);
                                 last_hit = pv.last_hit_dev[photon_id];
                                 triangle_index = -1;
@@ -516,7 +516,7 @@ k_raycast_wide(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                     if (!has_ray) {
                         hit_triangle[slot] = result;
                         hit_distance[slot] = 0.0f;
-                        if (result == HIT_RETRY) atomicAdd(retry_counter, 1u);
+                        if (result == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
                     }
                 }
             }
@@ -573,7 +573,6 @@ k_raycast_wide(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                                 spill[(size_t)(sp - WIDE_STACK) * PROP_BLOCK] = make_uint2(pw, __float_as_uint(pt));
                                 sp++;
                             } else {                                 // cannot happen: the host checked the tree's need
-                                if (COUNT && triangle_index != HIT_RETRY) cnt.steps--;   // counted again by the retry pass
                                 triangle_index = HIT_RETRY;
                             }
                         }
@@ -608,7 +607,7 @@ k_raycast_wide(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
         if (has_ray && !active) {
             hit_triangle[slot] = triangle_index;                 // record index, or a HIT_* code
             hit_distance[slot] = min_distance;
-            if (triangle_index == HIT_RETRY) atomicAdd(retry_counter, 1u);
+            if (triangle_index == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
             has_ray = false;
         }
     }
@@ -671,7 +670,8 @@ __device__ inline uint32_t group8_min_u32(uint32_t v)
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(COOP_WAVES_PER_EU, COOP_WAVES_PER_EU))) void
 k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
-               int32_t *hit_triangle, float *hit_distance, uint2 *spill_base, DeviceCounters *counters, int big_chunk)
+               int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint2 *spill_base, DeviceCounters *counters,
+               int big_chunk)
 {
     const int nthreads = (int)st->n, renorm = (int)st->renorm;
     if ((long long)blockIdx.x * 8 >= nthreads) return;
@@ -738,7 +738,6 @@ k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                         if (!moderate) {
                             result = HIT_RETRY;
                         } else {
-                            if (COUNT && j == 0) cnt.steps++;
                             rf = ray_fast(g, noid, inv_dir);
                             last_hit = pv.last_hit_dev[photon_id];
                             triangle_index = -1;
@@ -755,7 +754,7 @@ k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                 if (!has_ray && j == 0) {
                     hit_triangle[slot] = result;
                     hit_distance[slot] = 0.0f;
-                    if (result == HIT_RETRY) atomicAdd(retry_counter, 1u);
+                    if (result == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
                 }
             }
         }
@@ -806,7 +805,6 @@ k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                     sp += __popc(others);
                     cur = (uint32_t)__shfl((int)w, (int)(gshift + nj));
                     if (sp > COOP_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
-                        if (COUNT && j == 0) cnt.steps--;         // counted again by the retry pass
                         triangle_index = HIT_RETRY;
                         active = false; npend = 0; cur = WIDE_NONE; sp = 0;
                     }
@@ -856,7 +854,7 @@ k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
             if (j == 0) {
                 hit_triangle[slot] = triangle_index;                 // record index, or a HIT_* code
                 hit_distance[slot] = min_distance;
-                if (triangle_index == HIT_RETRY) atomicAdd(retry_counter, 1u);
+                if (triangle_index == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
             }
             has_ray = false;
         }
@@ -1057,8 +1055,13 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input
         float distance;
         int record = coop_cast<COUNT>(g, p.position, p.direction, last_hit_dev, stepping, distance, stack_n, stack_t, pending,
                                       spill, j, gshift, below, cnt);
-        // the general walk for the rays the wide walk cannot take (first lane of the group, then shared)
+        // the reference's own walk for the rays the wide walk cannot take, and for winners that are not
+        // regular (hit_is_regular): first lane of the group, then shared
         bool general = stepping && record == HIT_RETRY;
+        if (stepping && record >= 0) {
+            const float4 *t = g.tri + 3 * (size_t)record;
+            general = !record_hit_is_regular(g, t[0], t[1], t[2], p.position, p.direction, distance);
+        }
         if (__any(general)) {
             float d2 = 0.0f;
             int r2 = intersect_mesh_dev<STACK_LDS, PROP_BLOCK, COUNT>(g, p.position, p.direction, d2, last_hit_dev,
@@ -1107,41 +1110,30 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input
     }
 }
 
-// Second pass for the slots k_raycast_persistent marked HIT_RETRY (normally none): the general
-// walk (reference-exact slab test, stack spilling to scratch).  A small fixed grid strides over
-// the queue; it returns at once when the retry counter is zero.
+// Second pass for the rays the fast walks hand over (their queue slots are listed in retry_list):
+// 1/d not moderate, a winner that is not regular (hit_is_regular), a stack deeper than the spill.
+// They take the literal reference walk, intersect_mesh_strict.  ~1e-4 of the rays.
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
 k_raycast_retry(GeoView g, PhotonView pv, int first_photon, const StepState *st, const uint32_t *input_queue,
-                int32_t *hit_triangle, float *hit_distance, DeviceCounters *counters)
+                int32_t *hit_triangle, float *hit_distance, const uint32_t *retry_list, DeviceCounters *counters)
 {
-    const int nthreads = (int)st->n, renorm = (int)st->renorm;
-    const uint32_t *retry_counter = &st->retry;
+    const int nretry = (int)st->retry, renorm = (int)st->renorm;
     __shared__ uint32_t s_lds[TRAV_LDS_WORDS(STACK_LDS, PROP_BLOCK)];
-    if (*retry_counter == 0u) return;
+    if (nretry == 0) return;
     LaneCounters cnt = {0, 0, 0, 0};
-    int stride = gridDim.x * PROP_BLOCK;
-    for (int base = blockIdx.x * PROP_BLOCK; base < nthreads; base += stride) {
-        int id = base + threadIdx.x;
-        bool cast = false;
-        v3 position = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
-        int last_hit = -1, slot = first_photon + id;
-        if (id < nthreads && hit_triangle[slot] == HIT_RETRY) {
-            uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
-            position = load3(pv.pos, photon_id);
-            direction = load3(pv.dir, photon_id);
-            if (renorm) direction = direction / norm(direction);
-            last_hit = pv.last_hit_dev[photon_id];
-            cast = true;
-            if (COUNT) cnt.steps++;
-        }
-        if (!__any(cast)) continue;
+    const int stride = gridDim.x * PROP_BLOCK;
+    for (int k = blockIdx.x * PROP_BLOCK + threadIdx.x; k < nretry; k += stride) {      // lanes are independent here
+        const int slot = (int)retry_list[k];
+        uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
+        v3 position = load3(pv.pos, photon_id);
+        v3 direction = load3(pv.dir, photon_id);
+        if (renorm) direction = direction / norm(direction);
+        int last_hit = pv.last_hit_dev[photon_id];
         float dist;
-        int found = intersect_mesh_dev<STACK_LDS, PROP_BLOCK, COUNT>(g, position, direction, dist, last_hit, s_lds + threadIdx.x, cnt, cast);
-        if (cast) {
-            hit_triangle[slot] = found;
-            hit_distance[slot] = dist;
-        }
+        int found = intersect_mesh_dev<STACK_LDS, PROP_BLOCK, COUNT>(g, position, direction, dist, last_hit, s_lds + threadIdx.x, cnt, true);
+        hit_triangle[slot] = found;
+        hit_distance[slot] = dist;
     }
     unsigned long long ov = wave_sum_u64(cnt.overflows);
     if (COUNT) {
@@ -1157,21 +1149,39 @@ k_raycast_retry(GeoView g, PhotonView pv, int first_photon, const StepState *st,
 
 #define PHYS_BLOCK 512
 __global__ __launch_bounds__(PHYS_BLOCK) void
-k_physics(GeoView g, PhotonView pv, int first_photon, const StepState *st, const uint32_t *input_queue, uint32_t *output_queue,
+k_physics(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue, uint32_t *output_queue,
           const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base, int use_weights,
-          int scatter_first)
+          int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters)
 {
+    // Two passes per step.  Main pass (fixup = 0): every queue slot; a slot the ray cast handed to the
+    // strict walk (HIT_RETRY) is left alone, and so is a hit that is not REGULAR (hit_is_regular,
+    // propagate_device.h): its slot joins retry_list.  Fix-up pass (fixup = 1), after k_raycast_retry
+    // has walked those rays the reference's way: the listed slots only, results taken as they are.
     __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
-    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    const int nthreads = fixup ? (int)st->retry : (int)st->n, renorm = (int)st->renorm;
+    unsigned long long nsteps = 0;
     // the grid is sized for an upper bound of the photon count: blocks stride over the queue
     for (int block_base = blockIdx.x * PHYS_BLOCK; block_base < nthreads; block_base += gridDim.x * PHYS_BLOCK) {
     int id = block_base + threadIdx.x;
     bool alive = false;
     uint32_t photon_id = 0;
     if (id < nthreads) {
-        photon_id = input_queue ? input_queue[first_photon + id] : (uint32_t)(first_photon + id);
-        int tri = hit_triangle[first_photon + id];
-        if (tri != HIT_SKIP) {
+        const int slot = fixup ? (int)retry_list[id] : first_photon + id;
+        photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
+        int tri = hit_triangle[slot];
+        const float hit_dist = hit_distance[slot];
+        if (!fixup && tri >= 0) {
+            // is the fast walk's winner one the reference is sure to find too?
+            v3 o = load3(pv.pos, photon_id), d = load3(pv.dir, photon_id);
+            if (renorm) d = d / norm(d);
+            const float4 *t = g.tri + 3 * (size_t)tri;
+            if (!record_hit_is_regular(g, t[0], t[1], t[2], o, d, hit_dist)) {
+                retry_list[atomicAdd(&st->retry, 1u)] = (uint32_t)slot;
+                tri = HIT_RETRY;
+            }
+        }
+        if (tri != HIT_SKIP && tri != HIT_RETRY) {
+            if (tri != HIT_NAN) nsteps++;
             Photon p;
             p.position = load3(pv.pos, photon_id);
             p.direction = load3(pv.dir, photon_id);
@@ -1195,7 +1205,7 @@ k_physics(GeoView g, PhotonView pv, int first_photon, const StepState *st, const
                 p.history |= CHROMA_NO_HIT | CHROMA_NAN_ABORT;
             } else {
                 State s;
-                apply_hit_dev(s, p, g, tri, hit_distance[first_photon + id]);
+                apply_hit_dev(s, p, g, tri, hit_dist);
                 if (tri != -1) step_after_hit(p, s, rng, g, use_weights != 0, scatter_first);
                 // (a photon scattered or absorbed in the bulk forgets the triangle, photon.h:232,262,283)
                 pv.last_hit_dev[photon_id] = (p.last_hit_triangle < 0) ? -1 : tri;
@@ -1214,6 +1224,10 @@ k_physics(GeoView g, PhotonView pv, int first_photon, const StepState *st, const
     }
     if (output_queue) block_queue_append<PHYS_BLOCK / WAVE>(output_queue, alive, photon_id, s_counts);
     __syncthreads();        // s_counts is reused by the next round
+    }
+    if (counters) {
+        nsteps = wave_sum_u64(nsteps);
+        if (lane_id() == 0 && nsteps) atomicAdd(&counters->photon_steps, nsteps);
     }
 }
 
@@ -1582,22 +1596,32 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     do {                                                                                                               \
         if (coop)                                                                                                      \
             hipLaunchKernelGGL((k_raycast_coop<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,          \
-                               ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
+                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
         else if (wide)                                                                                                 \
             hipLaunchKernelGGL((k_raycast_wide<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,          \
-                               ctx->hit_triangle, ctx->hit_distance, ctx->wide_spill, ctx->d_counters, ctx->ray_chunk); \
+                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->wide_spill, ctx->d_counters, ctx->ray_chunk); \
         else                                                                                                           \
             hipLaunchKernelGGL((k_raycast_persistent<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,    \
-                               ctx->hit_triangle, ctx->hit_distance, ctx->d_counters);                                 \
+                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);                \
         if (ev) HIP_TRY(hipEventRecord(ev[1], ctx->stream));                                                            \
-        hipLaunchKernelGGL((k_raycast_retry<COUNT>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, st, q,        \
-                           ctx->hit_triangle, ctx->hit_distance, ctx->d_counters);                                     \
     } while (0)
     if (ctx->counting) RAYCAST_LAUNCH(true); else RAYCAST_LAUNCH(false);
 #undef RAYCAST_LAUNCH
+    // physics for every slot whose hit is regular; then the strict walk and the physics of the rest
     unsigned pblocks = (unsigned)std::min<long long>((n_upper + PHYS_BLOCK - 1) / PHYS_BLOCK, (long long)ctx->physics_blocks);
+    DeviceCounters *pc = ctx->counting ? ctx->d_counters : nullptr;
     hipLaunchKernelGGL(k_physics, dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, 0, st,
-                       q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first);
+                       q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
+                       ctx->retry_list, 0, pc);
+    if (ctx->counting)
+        hipLaunchKernelGGL((k_raycast_retry<true>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, st, q,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
+    else
+        hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, st, q,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
+    hipLaunchKernelGGL(k_physics, dim3(std::min(pblocks, 64u)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, 0, st,
+                       q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
+                       ctx->retry_list, 1, pc);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
@@ -1755,6 +1779,7 @@ int chroma_shutdown(chroma_ctx *ctx)
     if (ctx->hit_triangle) hipFree(ctx->hit_triangle);
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
     if (ctx->last_hit_dev) hipFree(ctx->last_hit_dev);
+    if (ctx->retry_list) hipFree(ctx->retry_list);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_words);
     hipHostFree(ctx->h_words);
@@ -1997,6 +2022,12 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
 #undef UP
     memcpy(v.world_origin, d->world_origin, sizeof v.world_origin);
     v.world_scale = d->world_scale;
+    {   // ~16 ulp of the largest world coordinate (hit_is_regular)
+        float maxabs = 0.0f;
+        for (int a = 0; a < 3; a++)
+            maxabs = std::max(maxabs, std::max(fabsf(d->world_origin[a]), fabsf(d->world_origin[a] + 65535.0f * d->world_scale)));
+        v.suspect_margin = 2e-6f * maxabs;
+    }
     v.wavelength_n = d->wavelength_n; v.wavelength_start = d->wavelength_start; v.wavelength_step = d->wavelength_step;
     v.time_n = d->time_n; v.time_start = d->time_start; v.time_step = d->time_step;
     v.nnodes = d->nnodes; v.ntriangles = d->ntriangles; v.nsolids = d->nsolids; v.nchannels = d->nchannels;
@@ -2191,14 +2222,16 @@ static int ensure_queues(chroma_ctx *ctx, size_t n)
     if (ctx->hit_triangle) hipFree(ctx->hit_triangle);
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
     if (ctx->last_hit_dev) hipFree(ctx->last_hit_dev);
+    if (ctx->retry_list) hipFree(ctx->retry_list);
     ctx->queue_a = ctx->queue_b = nullptr;
-    ctx->hit_triangle = nullptr; ctx->hit_distance = nullptr; ctx->last_hit_dev = nullptr;
+    ctx->hit_triangle = nullptr; ctx->hit_distance = nullptr; ctx->last_hit_dev = nullptr; ctx->retry_list = nullptr;
     ctx->queue_capacity = 0;
     HIP_TRY(hipMalloc((void **)&ctx->queue_a, (n + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->queue_b, (n + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->hit_triangle, (n + 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->hit_distance, (n + 1) * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&ctx->last_hit_dev, (n + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->retry_list, (n + 1) * sizeof(uint32_t)));
     ctx->queue_capacity = n + 1;
     return CHROMA_OK;
 }

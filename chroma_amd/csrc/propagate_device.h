@@ -74,13 +74,15 @@ __device__ inline bool intersect_triangle(v3 origin, v3 direction, v3 v0, v3 v1,
     return false;
 }
 
-// Slab test of intersect_box (intersect.h:107-147) for one child.  Returns tmin (the distance to
-// the box) or -1 when the ray misses it.  For an axis the ray is exactly parallel to (1/d = +-inf)
-// the reference skips the slab altogether (intersect.h:115,124,133), which makes such a ray walk
-// every box in its plane; here the parallel axis is a containment test instead: a box whose slab
-// does not contain the origin's coordinate cannot hold a triangle this ray hits (leaf boxes are
-// padded by one quantum, bvh.cu:181-185), so the hit found is the same while the walk stays short.
-__device__ inline float box_tmin(v3 origin, v3 noid, v3 inv_dir, v3 lower, v3 upper)
+// Slab test of intersect_box (intersect.h:107-147) for one child, in the reference's arithmetic.
+// Returns tmin (the distance to the box) or -1 when the ray misses it.  For an axis the ray is exactly
+// parallel to (1/d = +-inf) the reference skips the slab altogether (intersect.h:115,124,133), which
+// makes such a ray walk every box in its plane; here the parallel axis is a containment test with a
+// margin of one quantum `ws` instead: a box whose slab is more than a quantum away from the ray's
+// constant coordinate holds no triangle within a quantum of the ray, and Moeller-Trumbore accepts
+// nothing farther off than 1e-6 of an edge length (intersect.h:65-72) -- the hits found are the same
+// while the walk stays short.
+__device__ inline float box_tmin(v3 origin, v3 noid, v3 inv_dir, v3 lower, v3 upper, float ws)
 {
     float tmin = 0.0f, tmax = cm_inff();
     float t0, t1;
@@ -89,21 +91,106 @@ __device__ inline float box_tmin(v3 origin, v3 noid, v3 inv_dir, v3 lower, v3 up
         t1 = upper.x * inv_dir.x + noid.x;
         tmin = cm_fmaxf(tmin, cm_fminf(t0, t1));
         tmax = cm_fminf(tmax, cm_fmaxf(t0, t1));
-    } else if (origin.x < lower.x || origin.x > upper.x) return -1.0f;
+    } else if (origin.x < lower.x - ws || origin.x > upper.x + ws) return -1.0f;
     if (cm_isfinite(inv_dir.y)) {
         t0 = lower.y * inv_dir.y + noid.y;
         t1 = upper.y * inv_dir.y + noid.y;
         tmin = cm_fmaxf(tmin, cm_fminf(t0, t1));
         tmax = cm_fminf(tmax, cm_fmaxf(t0, t1));
-    } else if (origin.y < lower.y || origin.y > upper.y) return -1.0f;
+    } else if (origin.y < lower.y - ws || origin.y > upper.y + ws) return -1.0f;
     if (cm_isfinite(inv_dir.z)) {
         t0 = lower.z * inv_dir.z + noid.z;
         t1 = upper.z * inv_dir.z + noid.z;
         tmin = cm_fmaxf(tmin, cm_fminf(t0, t1));
         tmax = cm_fminf(tmax, cm_fmaxf(t0, t1));
-    } else if (origin.z < lower.z || origin.z > upper.z) return -1.0f;
+    } else if (origin.z < lower.z - ws || origin.z > upper.z + ws) return -1.0f;
     if (tmin > tmax) return -1.0f;
     return tmin;
+}
+
+// ---- when is a fast walk's answer the reference's? ---------------------------------------------
+// The fast walks (fused slab test on boxes grown by a quantum, postponed triangle tests, or another
+// tree altogether) test a SUPERSET of the triangles the reference tests.  The reference's own box
+// test is not conservative: it evaluates a box as world_origin + q * world_scale in float32
+// (geometry.h:31-47), which can round the padding of a leaf box away (an upper face sits only a
+// fraction of a quantum above the triangle), so a ray that hits a triangle right at the face of its
+// leaf box can miss that box -- and the triangle -- in the reference.  A fast walk finds such a hit.
+// So the winner W of a fast walk is accepted only if the reference is sure to test W:
+//     the reference's slab test (its arithmetic, literally) passes for W's leaf box, with a box
+//     distance not beyond W's hit distance.
+// That is enough: the float boxes of W's ancestors contain its leaf box (the conversion and the slab
+// arithmetic are monotone), so they pass too; none of them can be pruned before W is tested, because
+// pruning needs a hit nearer than the box distance, hence nearer than W, and any such hit the reference
+// can find the fast walk has found as well (superset) -- W would not be its winner.  With W tested,
+// the reference's result is the (distance, rank)-minimal hit among the triangles it tests, which is W.
+// A ray whose winner fails the test is walked again by intersect_mesh_strict, the literal reference
+// loop.  Measured: a few per 1e8 random rays; rays aimed at mesh vertices and edges find them readily
+// (tests/test_gpu_parity.py::test_exact_ties_follow_the_reference_test_order).
+__device__ inline bool reference_tests_leaf(const GeoView &g, uint32_t bx, uint32_t by, uint32_t bz, v3 origin, v3 direction, float t)
+{
+    const float ws = g.world_scale;
+    const v3 noid = (-origin) / direction;
+    const v3 inv_dir = 1.0f / direction;
+    v3 lower = mk3(g.world_origin[0] + (float)(bx & 0xFFFFu) * ws, g.world_origin[1] + (float)(by & 0xFFFFu) * ws,
+                   g.world_origin[2] + (float)(bz & 0xFFFFu) * ws);
+    v3 upper = mk3(g.world_origin[0] + (float)(bx >> 16) * ws, g.world_origin[1] + (float)(by >> 16) * ws,
+                   g.world_origin[2] + (float)(bz >> 16) * ws);
+    // intersect_box (intersect.h:107-147): a slab is skipped when 1/d is not finite
+    float tmin = 0.0f, tmax = cm_inff();
+    float t0, t1;
+    if (cm_isfinite(inv_dir.x)) {
+        t0 = lower.x * inv_dir.x + noid.x; t1 = upper.x * inv_dir.x + noid.x;
+        tmin = cm_fmaxf(tmin, cm_fminf(t0, t1)); tmax = cm_fminf(tmax, cm_fmaxf(t0, t1));
+    }
+    if (cm_isfinite(inv_dir.y)) {
+        t0 = lower.y * inv_dir.y + noid.y; t1 = upper.y * inv_dir.y + noid.y;
+        tmin = cm_fmaxf(tmin, cm_fminf(t0, t1)); tmax = cm_fminf(tmax, cm_fmaxf(t0, t1));
+    }
+    if (cm_isfinite(inv_dir.z)) {
+        t0 = lower.z * inv_dir.z + noid.z; t1 = upper.z * inv_dir.z + noid.z;
+        tmin = cm_fmaxf(tmin, cm_fminf(t0, t1)); tmax = cm_fminf(tmax, cm_fmaxf(t0, t1));
+    }
+    return !(tmin > tmax) && !(tmin > t);
+}
+// The same question asked with the triangle's vertices (the per-step kernels do not carry the box of a
+// postponed triangle).  Cheap part first: the leaf box reaches at least a quantum below the vertices'
+// minimum and, in exact arithmetic, above their maximum, so a hit point between (minimum - ws/2) and
+// (maximum - margin) is inside the float box whatever the rounding did (margin ~ 32 ulp of the largest
+// world coordinate): the slab test passes.  Only a hit within the margin of a maximum face (~1e-3 of
+// the hits) takes the exact route: the leaf box by the reference's rule, then the test above.
+__device__ inline void leaf_words(const GeoView &g, v3 v0, v3 v1, v3 v2, uint32_t &bx, uint32_t &by, uint32_t &bz);
+__device__ inline bool record_hit_is_regular(const GeoView &g, float4 a, float4 b, float4 c, v3 origin, v3 direction, float t)
+{
+    const float m = 2.0f * g.suspect_margin, half = 0.5f * g.world_scale;
+    float px = origin.x + t * direction.x, py = origin.y + t * direction.y, pz = origin.z + t * direction.z;
+    float lx = fminf(fminf(a.x, b.x), c.x), hx = fmaxf(fmaxf(a.x, b.x), c.x);
+    float ly = fminf(fminf(a.y, b.y), c.y), hy = fmaxf(fmaxf(a.y, b.y), c.y);
+    float lz = fminf(fminf(a.z, b.z), c.z), hz = fmaxf(fmaxf(a.z, b.z), c.z);
+    // (a leaf whose lower bound quantises to 0 is not padded downwards, bvh.cu:181: exact route)
+    bool low_ok = px >= lx - half && py >= ly - half && pz >= lz - half &&
+                  lx >= g.world_origin[0] + g.world_scale && ly >= g.world_origin[1] + g.world_scale &&
+                  lz >= g.world_origin[2] + g.world_scale;
+    if (low_ok && px <= hx - m && py <= hy - m && pz <= hz - m) return true;
+    uint32_t bx, by, bz;
+    leaf_words(g, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, bz);
+    return reference_tests_leaf(g, bx, by, bz, origin, direction, t);
+}
+
+// the leaf box of a triangle by the reference's rule (cuda/bvh.cu:149-203: truncate, one quantum down,
+// one up), for the lane-per-ray kernels, which do not carry the box of a postponed triangle
+__device__ inline void leaf_words(const GeoView &g, v3 v0, v3 v1, v3 v2, uint32_t &bx, uint32_t &by, uint32_t &bz)
+{
+    const float ws = g.world_scale;
+    float lo[3] = {fminf(fminf(v0.x, v1.x), v2.x), fminf(fminf(v0.y, v1.y), v2.y), fminf(fminf(v0.z, v1.z), v2.z)};
+    float hi[3] = {fmaxf(fmaxf(v0.x, v1.x), v2.x), fmaxf(fmaxf(v0.y, v1.y), v2.y), fmaxf(fmaxf(v0.z, v1.z), v2.z)};
+    uint32_t w[3];
+    for (int k = 0; k < 3; k++) {
+        uint32_t ql = (uint32_t)((lo[k] - g.world_origin[k]) / ws);
+        if (ql > 0) ql--;
+        uint32_t qu = (uint32_t)((hi[k] - g.world_origin[k]) / ws) + 1u;
+        w[k] = ql | qu << 16;
+    }
+    bx = w[0]; by = w[1]; bz = w[2];
 }
 
 // pruning rule of intersect_node (mesh.h:16-34) given the box distance
@@ -166,149 +253,87 @@ __device__ inline float box_tmin_fast(const RayFast &r, uint4 nd)
     return (tmin > tmax) ? -1.0f : tmin;
 }
 
-// intersect_mesh (mesh.h:42-118).  Every lane walks its own ray through the tree in the
-// reference's order -- children of a range first to last, inner hits pushed, the last pushed
-// range walked next -- but the loop is organised for a 64-wide wavefront:
-//   * node phase: one node per lane per iteration (fetch, slab test, push or note the leaf); the
-//     body is short and the same for every lane, so lanes stay converged;
-//   * leaf phase: leaves whose box passed are only NOTED (FIFO of TRAV_PENDING per lane in LDS);
-//     when some lane's FIFO is full, or every lane is done, the wave runs the Moeller-Trumbore
-//     tests together, oldest first.
-// Postponing a triangle test only delays the pruning bound (mesh.h:23-29): the walk visits a
-// superset of the reference's nodes and tests a superset of its triangles in the same relative
-// order; an extra triangle lies in a box farther than the current best hit, so it can neither win
-// nor tie.  The returned (triangle, distance) is therefore the reference's, bit for bit.
-// FAST selects the slab test: box_tmin_fast (above) or the reference-exact box_tmin.
-template <int LDS_N, int BLOCK, bool COUNT, bool FAST>
-__device__ inline int intersect_mesh_walk(const GeoView &g, v3 origin, v3 direction, v3 noid, v3 inv_dir,
-                                          float &min_distance, int last_hit_triangle, uint32_t *lds,
-                                          LaneCounters &cnt, bool lane_on)
+// intersect_mesh (mesh.h:42-118), literally: the reference's order, its box arithmetic, every triangle
+// tested the moment its leaf box is entered.  Lanes are independent (no wave votes), so it is slow and
+// used where exactness matters more than speed: rays handed over by the fast walks, the fused
+// lane-per-photon kernel, distance_to_mesh.  Works on triangle RECORD indices in and out.
+template <int LDS_N, int BLOCK, bool COUNT>
+__device__ inline int intersect_mesh_strict(const GeoView &g, v3 origin, v3 direction, float &min_distance,
+                                            int last_hit_record, uint32_t *lds, LaneCounters &cnt, bool lane_on)
 {
     int triangle_index = -1;
     min_distance = -1.0f;
-
+    if (!lane_on) return -1;
+    const v3 noid = (-origin) / direction;
+    const v3 inv_dir = 1.0f / direction;
     const v3 wo = mk3(g.world_origin[0], g.world_origin[1], g.world_origin[2]);
     const float ws = g.world_scale;
-    RayFast rf;
-    if (FAST) rf = ray_fast(g, noid, inv_dir);
-
-#define NODE_LO(nd) mk3(wo.x + (float)((nd).x & 0xFFFFu) * ws, wo.y + (float)((nd).y & 0xFFFFu) * ws, wo.z + (float)((nd).z & 0xFFFFu) * ws)
-#define NODE_HI(nd) mk3(wo.x + (float)((nd).x >> 16) * ws, wo.y + (float)((nd).y >> 16) * ws, wo.z + (float)((nd).z >> 16) * ws)
-#define NODE_TMIN(nd) (FAST ? box_tmin_fast(rf, nd) : box_tmin(origin, noid, inv_dir, NODE_LO(nd), NODE_HI(nd)))
-
+#define S_LO(nd) mk3(wo.x + (float)((nd).x & 0xFFFFu) * ws, wo.y + (float)((nd).y & 0xFFFFu) * ws, wo.z + (float)((nd).z & 0xFFFFu) * ws)
+#define S_HI(nd) mk3(wo.x + (float)((nd).x >> 16) * ws, wo.y + (float)((nd).y >> 16) * ws, wo.z + (float)((nd).z >> 16) * ws)
     TravStack<LDS_N, BLOCK> stack;
     stack.lds = lds;
-    uint32_t *pending = lds + LDS_N * BLOCK;
-    int sp = 0, npend = 0;
-    uint32_t cur = 1, end = 0;            // empty range
-    bool active = false;
-    if (lane_on) {
-        uint4 root = g.nodes[0];
-        if (node_passes(NODE_TMIN(root), min_distance)) {
-            active = true;
-            cur = root.w & ~CHROMA_NCHILD_MASK;
-            end = cur + (root.w >> CHROMA_CHILD_BITS) - 1;
-        }
-    }
-
-    // all 64 lanes stay in this loop until the whole wave is done (wave-uniform branches only)
-    while (__any(active)) {
-        // ---- node phase
-        do {
-            if (active) {
-                if (cur > end) {
-                    if (sp == 0) {
-                        active = false;
-                    } else {
-                        sp--;
-                        uint32_t w = stack.get(sp);
-                        cur = w & ~CHROMA_NCHILD_MASK;
-                        end = cur + (w >> CHROMA_CHILD_BITS) - 1;
-                    }
-                }
-                if (active) {
-                    uint4 nd = g.nodes[cur];
-                    cur++;
-                    if (COUNT) cnt.nodes++;
-                    float tmin = NODE_TMIN(nd);
-                    if (node_passes(tmin, min_distance)) {
-                        uint32_t nd_child = nd.w & ~CHROMA_NCHILD_MASK;
-                        if ((nd.w >> CHROMA_CHILD_BITS) == 0) {
-                            if ((int)nd_child != last_hit_triangle) {
-                                pending[npend * BLOCK] = nd_child;
-                                npend++;
-                            }
-                        } else if (sp >= LDS_N + STACK_SCRATCH) {   // cannot happen when the host check passed
-                            cnt.overflows++;
-                            active = false;
-                        } else {
-                            stack.put(sp, nd.w);
-                            sp++;
+    uint4 root = g.nodes[0];
+    if (!node_passes(box_tmin(origin, noid, inv_dir, S_LO(root), S_HI(root), ws), min_distance)) return -1;
+    int sp = 0;
+    stack.put(sp++, root.w);
+    while (sp > 0) {
+        uint32_t w = stack.get(--sp);
+        uint32_t first = w & ~CHROMA_NCHILD_MASK, n = w >> CHROMA_CHILD_BITS;
+        // the children of a range are contiguous: fetched four at a time (one latency per four),
+        // tested strictly in order
+        for (uint32_t i0 = first; i0 < first + n; i0 += 4) {
+            const uint32_t last = first + n - 1;
+            uint4 quad[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) quad[k] = g.nodes[min(i0 + (uint32_t)k, last)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (i0 + (uint32_t)k > last) break;
+                const uint4 nd = quad[k];
+                if (COUNT) cnt.nodes++;
+                if (!node_passes(box_tmin(origin, noid, inv_dir, S_LO(nd), S_HI(nd), ws), min_distance)) continue;
+                uint32_t child = nd.w & ~CHROMA_NCHILD_MASK;
+                if ((nd.w >> CHROMA_CHILD_BITS) == 0) {
+                    if ((int)child == last_hit_record) continue;
+                    if (COUNT) cnt.tris++;
+                    const float4 *t = g.tri + 3 * (size_t)child;
+                    float4 a = t[0], b = t[1], c = t[2];
+                    float distance;
+                    if (intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance)) {
+                        if (triangle_index == -1 || distance < min_distance) {
+                            triangle_index = (int)child;
+                            min_distance = distance;
                         }
                     }
-                }
-            }
-        } while (!__any(npend >= TRAV_PENDING) && __any(active));
-
-        // ---- leaf phase: postponed triangle tests, oldest first (the reference's order)
-        for (int j = 0; __any(j < npend); j++) {
-            if (j < npend) {
-                uint32_t tri = pending[j * BLOCK];
-                if (COUNT) cnt.tris++;
-                const float4 *t = g.tri + 3 * (size_t)tri;
-                float4 a = t[0], b = t[1], c = t[2];
-                float distance;
-                if (intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance)) {
-                    if (triangle_index == -1 || distance < min_distance) {
-                        triangle_index = (int)tri;
-                        min_distance = distance;
-                    }
+                } else if (sp >= LDS_N + STACK_SCRATCH) {      // cannot happen when the host check passed
+                    cnt.overflows++;
+                    return triangle_index;
+                } else {
+                    stack.put(sp++, nd.w);
                 }
             }
         }
-        npend = 0;
     }
-#undef NODE_LO
-#undef NODE_HI
-#undef NODE_TMIN
+#undef S_LO
+#undef S_HI
     return triangle_index;
 }
 
+// by triangle id in and out (fused kernel, distance_to_mesh)
 template <int LDS_N, int BLOCK, bool COUNT>
 __device__ inline int intersect_mesh(const GeoView &g, v3 origin, v3 direction, float &min_distance,
                                      int last_hit_triangle, uint32_t *lds, LaneCounters &cnt, bool lane_on = true)
 {
-    const v3 noid = (-origin) / direction;
-    const v3 inv_dir = 1.0f / direction;
-    // the walk works on device triangle indices (leaf order, see device_common.h)
     int last_hit_dev = (lane_on && last_hit_triangle >= 0) ? (int)g.tri_to_dev[last_hit_triangle] : -1;
-    int found;
-    // |1/d| < 1e30 on all axes (false for inf and NaN): the whole wave takes the fast slab test
-    bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
-                    cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
-    if (__any(lane_on && !moderate))
-        found = intersect_mesh_walk<LDS_N, BLOCK, COUNT, false>(g, origin, direction, noid, inv_dir, min_distance,
-                                                                last_hit_dev, lds, cnt, lane_on);
-    else
-        found = intersect_mesh_walk<LDS_N, BLOCK, COUNT, true>(g, origin, direction, noid, inv_dir, min_distance,
-                                                               last_hit_dev, lds, cnt, lane_on);
+    int found = intersect_mesh_strict<LDS_N, BLOCK, COUNT>(g, origin, direction, min_distance, last_hit_dev, lds, cnt, lane_on);
     return (found >= 0) ? (int)g.dev_to_tri[found] : found;
 }
-
-// the same on triangle RECORD indices in and out (per-step kernels)
+// by record index in and out (retry pass, tail kernel)
 template <int LDS_N, int BLOCK, bool COUNT>
 __device__ inline int intersect_mesh_dev(const GeoView &g, v3 origin, v3 direction, float &min_distance,
                                          int last_hit_dev, uint32_t *lds, LaneCounters &cnt, bool lane_on = true)
 {
-    const v3 noid = (-origin) / direction;
-    const v3 inv_dir = 1.0f / direction;
-    bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
-                    cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
-    if (__any(lane_on && !moderate))
-        return intersect_mesh_walk<LDS_N, BLOCK, COUNT, false>(g, origin, direction, noid, inv_dir, min_distance,
-                                                               last_hit_dev, lds, cnt, lane_on);
-    return intersect_mesh_walk<LDS_N, BLOCK, COUNT, true>(g, origin, direction, noid, inv_dir, min_distance,
-                                                          last_hit_dev, lds, cnt, lane_on);
+    return intersect_mesh_strict<LDS_N, BLOCK, COUNT>(g, origin, direction, min_distance, last_hit_dev, lds, cnt, lane_on);
 }
 
 // ---- random.h / interpolate.h -----------------------------------------------------------------

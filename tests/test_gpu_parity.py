@@ -408,3 +408,76 @@ def test_c_abi_rejects_bad_input(gpu, tiny_geometry):
     for view in b.iterate_copies():
         view.propagate(gg, rng_b, max_steps=20)
     assert np.array_equal(a.get().flags, b.get().flags) and np.array_equal(a.get().t, b.get().t)
+
+
+def _aimed_photons(geometry, origin, n_min):
+    """Photons from ``origin`` aimed exactly at mesh vertices, edge midpoints and triangle centroids:
+    a ray through a vertex or an edge meets several triangles at (often bit-for-bit) the same
+    distance, which is where the ORDER of the triangle tests decides the reference's answer."""
+    m = geometry.mesh
+    v = m.vertices.astype(np.float64)
+    t = m.triangles
+    rng = np.random.default_rng(5)
+    pick = rng.choice(len(t), size=min(len(t), 6000), replace=False)
+    tri = v[t[pick]]                                           # [k][3][3]
+    targets = np.concatenate([tri.reshape(-1, 3), 0.5 * (tri[:, 0] + tri[:, 1]), 0.5 * (tri[:, 1] + tri[:, 2]),
+                              0.5 * (tri[:, 2] + tri[:, 0]), tri.mean(axis=1)])
+    d = targets - np.asarray(origin, dtype=np.float64)
+    d = d[np.linalg.norm(d, axis=1) > 1e-9]
+    reps = int(np.ceil(n_min / float(len(d))))
+    d = np.tile(d, (reps, 1))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    pol = np.cross(d, np.roll(d, 1, axis=1) + 1e-3)
+    pol /= np.linalg.norm(pol, axis=1)[:, None]
+    n = len(d)
+    return Photons(np.tile(np.asarray(origin, dtype=float), (n, 1)), d, pol, np.full(n, 400.0))
+
+
+@pytest.mark.parametrize('count', ['large', 'small'])
+def test_exact_ties_follow_the_reference_test_order(gpu, oracle_mod, tiny_geometry, count):
+    """Rays through vertices and edges: every walk (8 lanes per ray over the SAH tree, one lane per
+    ray, the reference tree in the reference's order; per-step launches and the fused tail) returns
+    the triangle the reference's test order picks."""
+    ph = _aimed_photons(tiny_geometry, (0.0, 0.0, 0.0), 20000 if count == 'large' else 3000)
+    if count == 'small':
+        ph = ph[:3000]                                        # fewer than 8192: the fused tail kernel from step 0
+    gg, gp, got, want, counters, stats, ostats = run_both(gpu, oracle_mod, tiny_geometry, ph, max_steps=4)
+    assert_bit_exact(got, want, 'aimed rays')
+    # the case is not vacuous: some of these rays do hit several triangles at one distance
+    from chroma_amd.gpu.geometry import pack_geometry
+    dist, tri, _ = oracle_mod.distance_to_mesh(pack_geometry(tiny_geometry), ph.pos[:4000], ph.dir[:4000])
+    assert (tri >= 0).mean() > 0.9
+    for mode in ('wide', 'reference'):
+        gpu.get_context().set_walk(mode)
+        try:
+            gp2 = gpu.GPUPhotons(ph)
+            gp2.propagate(gg, gpu.get_rng_states(64 * 1024, seed=12345), max_steps=4)
+        finally:
+            gpu.get_context().set_walk('coop')
+        assert_bit_exact(gp2.get(), want, 'aimed rays, %s walk' % mode)
+
+
+def test_edge_inputs_in_a_large_batch(gpu, oracle_mod, tiny_geometry):
+    """Terminal, NaN, exactly axis-parallel, outside-the-world and repeated-last-hit photons inside a
+    batch large enough for per-step launches (>= 8192 alive): same as the oracle, bit for bit."""
+    ph = bomb(24000, 17)
+    n = len(ph)
+    ph.flags[100:200] = event.BULK_ABSORB                      # terminal: untouched
+    ph.dir[100:200] *= 2.5
+    ph.pos[300, 2] = np.nan                                    # NaN guard
+    ph.dir[301, 0] = np.nan
+    axes = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1],
+                     [1, 1, 0], [0, 1, 1], [1, 0, -1]], dtype=float)
+    ph.dir[400:400 + 9 * 40] = np.tile(axes, (40, 1))         # exactly parallel to one or two axes (1/d = inf)
+    ph.pos[400:400 + 9 * 40] += np.repeat(np.linspace(-300, 300, 40), 9)[:, None] * np.array([0.3, 0.7, -0.2])
+    ph.pos[1000:1100] = 1e6                                    # outside the world box
+    ph.dir[1000:1050] = [1.0, 0, 0]                            # ... pointing away
+    ph.dir[1050:1100] = [-1.0, -1.0, -1.0]                     # ... pointing at it
+    ph.last_hit_triangles[2000:2200] = np.arange(200)          # a last hit that is not on the ray: no effect
+    gg, gp, got, want, counters, stats, ostats = run_both(gpu, oracle_mod, tiny_geometry, ph, max_steps=20)
+    assert_bit_exact(got, want, 'edge inputs, large batch')
+    assert np.array_equal(gp.rng_counters.get(), counters)
+    assert (got.flags[100:200] == event.BULK_ABSORB).all() and np.array_equal(got.dir[100:200], ph.dir[100:200])
+    assert got.flags[300] == (event.NO_HIT | event.NAN_ABORT) and got.flags[301] == (event.NO_HIT | event.NAN_ABORT)
+    assert (got.flags[1000:1050] == event.NO_HIT).all()
+    assert stats['launches'] == ostats['launches'] and stats['photon_steps'] == ostats['photon_steps']
