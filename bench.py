@@ -229,6 +229,20 @@ def main():
                         'sample': '%d photons of the same bomb on %s, oracle/chroma_oracle.c on %d host threads, '
                                   'propagate + hit histogram, %.1f s wall' % (sample, args.config, cores, dt)}
         log('cpu baseline: %.3g photons/s on %d threads' % (sample / dt, cores))
+        if args.config == 'tiny':
+            # the pure-NumPy restatement, 1e4 photons, one core (numpy is single-threaded here)
+            from oracle import numpy_propagate as npp
+            tab = npp.Tables(packed_for_cpu)
+            ph1 = oracle.generate_bomb(10_000, seed=ENGINE_SEED, id_base=0, wavelength_lo=wl_lo, wavelength_hi=wl_hi)
+            npp.propagate(packed_for_cpu, ph1, seed=1, max_steps=args.max_steps, tables=tab)          # warm-up
+            t0 = time.perf_counter()
+            reps = 3
+            for r in range(reps):
+                npp.propagate(packed_for_cpu, ph1, seed=2 + r, max_steps=args.max_steps, tables=tab)
+            dtn = (time.perf_counter() - t0) / reps
+            cpu_baseline['numpy_c1'] = {'value': 10_000 / dtn, 'unit': 'photons/s', 'cores': 1,
+                                        'sample': '1e4 photons of the same bomb, oracle/numpy_propagate.py, mean of %d runs, %.2f s each' % (reps, dtn)}
+            log('numpy C1 baseline: %.3g photons/s on 1 core' % (10_000 / dtn))
 
     if rank == 0:
         result = {

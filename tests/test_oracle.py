@@ -172,3 +172,29 @@ def test_daq_oracle_time_and_charge_spread(oracle_mod):
     # nothing detected -> nothing hit; weight 0 -> nothing hit
     t, q, hist, hit = oracle_mod.run_daq(pk, end, tables, unit, seed=2, weight=0.0)
     assert not hit.any() and q.sum() == 0
+
+
+def test_numpy_restatement_agrees_with_the_c_oracle(oracle_mod, tiny_packed):
+    """oracle/numpy_propagate.py (the "pure NumPy" figure of BASELINE.md section 5, C1): its ray cast
+    returns the C oracle's triangles and distances, and its histories agree statistically (its random
+    numbers are numpy's, so not photon by photon)."""
+    from oracle import numpy_propagate as npp
+    from chroma_amd import event
+    ph = oracle_mod.generate_bomb(10000, seed=20240502)
+    tab = npp.Tables(tiny_packed)
+    d = (ph.dir / np.linalg.norm(ph.dir, axis=1)[:, None]).astype(np.float32)
+    tri, dist = npp.intersect_mesh(tab, ph.pos.astype(np.float32), d, np.full(len(ph), -1))
+    odist, otri, _ = oracle_mod.distance_to_mesh(tiny_packed, ph.pos, ph.dir)
+    assert np.array_equal(tri, otri)
+    hit = otri >= 0
+    assert np.array_equal(dist[hit].view(np.uint32), odist[hit].view(np.uint32))
+    out = npp.propagate(tiny_packed, ph, seed=1, max_steps=100, tables=tab)
+    want, _, _ = oracle_mod.propagate(tiny_packed, ph, seed=12345, max_steps=100)
+    assert ((out.flags & event.TERMINAL_MASK) != 0).all()
+    n = float(len(ph))
+    for name in ('BULK_ABSORB', 'SURFACE_DETECT', 'SURFACE_ABSORB', 'RAYLEIGH_SCATTER', 'REFLECT_DIFFUSE', 'REFLECT_SPECULAR'):
+        bit = getattr(event, name)
+        a, b = ((out.flags & bit) != 0).sum(), ((want.flags & bit) != 0).sum()
+        sigma = np.sqrt(a + b + 1.0)                          # two independent Poisson-like counts
+        assert abs(a - b) < 5 * sigma, (name, a, b)
+    assert not ((out.flags & (event.NO_HIT | event.NAN_ABORT)) != 0).any()
