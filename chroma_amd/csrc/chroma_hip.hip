@@ -195,20 +195,20 @@ k_propagate(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint
     if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
 }
 
-// ---- one step split in two launches (used while many photons are alive) ------------------------
+// ---- one step as separate launches -----------------------------------------------------------------
 // The ray cast needs few registers and benefits from many resident waves; the physics needs many
-// registers and little time.  k_raycast writes (triangle, distance) per queue slot, k_physics
-// consumes them.  Together they perform exactly one iteration of the loop of k_propagate for every
-// queued photon, with identical arithmetic (both re-normalise dir/pol on load like propagate.cu:248,250).
+// registers and little time.  A ray-cast kernel writes (triangle record, distance) per queue slot,
+// k_physics consumes them.  Together they perform exactly one iteration of the loop of k_propagate
+// for every queued photon, with identical arithmetic (both re-normalise dir/pol on load like
+// propagate.cu:248,250 when the step opens a launch in the reference's sense, see k_step_begin).
 #define HIT_SKIP (-3)      // photon already terminal: untouched (propagate.cu:258)
 #define HIT_NAN  (-2)      // NaN guard fired (propagate.cu:270-273)
 
 // ---- device-side step control ---------------------------------------------------------------------
 // chroma_propagate enqueues its steps without waiting for any of them: how many photons a step has
 // (the tail of its input queue), whether its launch re-normalises (the reference's launch policy,
-// chroma/gpu/photon.py:225-252) and the ray-cast work counters live in this block, written by
-// k_step_begin at the head of every step and read by the step's kernels.
-
+// chroma/gpu/photon.py:225-252) and the ray-cast work counters live in StepState (top of this file),
+// written by k_step_begin at the head of every step and read by the step's kernels.
 __global__ void k_step_begin(const uint32_t *in_queue, uint32_t *out_queue, StepState *st, uint32_t few)
 {
     const uint32_t n = in_queue[0] - 1u;
@@ -1056,7 +1056,7 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input
         int record = coop_cast<COUNT>(g, p.position, p.direction, last_hit_dev, stepping, distance, stack_n, stack_t, pending,
                                       spill, j, gshift, below, cnt);
         // the reference's own walk for the rays the wide walk cannot take, and for winners that are not
-        // regular (hit_is_regular): first lane of the group, then shared
+        // regular (record_hit_is_regular): first lane of the group, then shared
         bool general = stepping && record == HIT_RETRY;
         if (stepping && record >= 0) {
             const float4 *t = g.tri + 3 * (size_t)record;
@@ -1111,7 +1111,7 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input
 }
 
 // Second pass for the rays the fast walks hand over (their queue slots are listed in retry_list):
-// 1/d not moderate, a winner that is not regular (hit_is_regular), a stack deeper than the spill.
+// 1/d not moderate, a winner that is not regular (record_hit_is_regular), a stack deeper than the spill.
 // They take the literal reference walk, intersect_mesh_strict.  ~1e-4 of the rays.
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
@@ -1154,7 +1154,7 @@ k_physics(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint3
           int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters)
 {
     // Two passes per step.  Main pass (fixup = 0): every queue slot; a slot the ray cast handed to the
-    // strict walk (HIT_RETRY) is left alone, and so is a hit that is not REGULAR (hit_is_regular,
+    // strict walk (HIT_RETRY) is left alone, and so is a hit that is not REGULAR (record_hit_is_regular,
     // propagate_device.h): its slot joins retry_list.  Fix-up pass (fixup = 1), after k_raycast_retry
     // has walked those rays the reference's way: the listed slots only, results taken as they are.
     __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
@@ -2022,7 +2022,7 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
 #undef UP
     memcpy(v.world_origin, d->world_origin, sizeof v.world_origin);
     v.world_scale = d->world_scale;
-    {   // ~16 ulp of the largest world coordinate (hit_is_regular)
+    {   // ~16 ulp of the largest world coordinate (record_hit_is_regular)
         float maxabs = 0.0f;
         for (int a = 0; a < 3; a++)
             maxabs = std::max(maxabs, std::max(fabsf(d->world_origin[a]), fabsf(d->world_origin[a] + 65535.0f * d->world_scale)));

@@ -72,7 +72,7 @@ struct GeoView {
     const int32_t  *solid_id_to_channel_index;
     float world_origin[3];
     float world_scale;
-    float suspect_margin;            // see hit_is_regular (propagate_device.h)
+    float suspect_margin;            // see record_hit_is_regular (propagate_device.h)
     uint32_t wavelength_n; float wavelength_start, wavelength_step;
     uint32_t time_n;       float time_start, time_step;
     uint32_t nnodes, ntriangles, nsolids, nchannels, nwide;
