@@ -18,10 +18,10 @@ d = np.column_stack([c * np.cos(theta), c * np.sin(theta), u]).astype(np.float32
 pol = np.cross(d, [0, 0, 1.0]).astype(np.float32); pol /= np.linalg.norm(pol, axis=1)[:, None]
 for label, order in (('random', np.arange(n)), ('sorted by direction', argsort_direction(d))):
     ph = Photons(np.zeros((n, 3), np.float32), d[order], pol[order], np.full(n, 400.0, np.float32))
-    for steps in (1, 2, 3):
+    for steps in (1, 2, 3, 100):
         gp = gpu.GPUPhotons(ph)
         rs = gpu.get_rng_states(1, seed=5)
         st = {}
         gp.propagate(gg, rs, max_steps=steps, stats=st, time_kernels=True)
-        print('%-20s max_steps=%d: kernels %.1f ms in %d launches' % (label, steps, st['kernel_ms'], st['launches']), flush=True)
+        print('%-20s max_steps=%d: kernels %.1f ms (ray cast %.1f ms) in %d launches' % (label, steps, st['kernel_ms'], st['raycast_ms'], st['launches']), flush=True)
         del gp
