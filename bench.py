@@ -38,7 +38,7 @@ def log(*a):
         print('[bench]', *a, file=sys.stderr, flush=True)
 
 
-RAYCAST_KERNEL = {'reference': 'k_raycast_persistent', 'wide': 'k_raycast_wide'}.get(os.environ.get('CHROMA_WALK', ''), 'k_raycast_coop')
+RAYCAST_KERNEL = {'reference': 'k_raycast_persistent', 'wide': 'k_raycast_wide', 'coop': 'k_raycast_coop'}.get(os.environ.get('CHROMA_WALK', ''), 'k_raycast_quad')
 
 
 def main():
@@ -190,7 +190,7 @@ def main():
     kernel_s = stats['kernel_ms'] / 1e3
     launches = max(1, stats['launches'])
     path_achieved = (bytes_per_photon * nphotons * args.steps) / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    # dominant kernel: the ray cast (k_raycast_coop; the retry pass after it is normally empty).
+    # dominant kernel: the ray cast (k_raycast_quad; the retry pass after it is normally empty).
     # Algorithmic bytes per photon step: 16 B per child entry fetched (a 128-B wide node = 8 entries)
     # + 48 B per triangle tested + 36 B ray state read + 8 B hit written
     ray_s = stats['raycast_ms'] / 1e3

@@ -73,11 +73,12 @@ struct chroma_ctx {
     int wide_waves = 256 * 14;             // same for k_raycast_wide (11 KB of LDS per wave)
     uint2 *wide_spill = nullptr;           // [wide_waves][WIDE_SPILL][64] stack entries beyond the LDS part
     int coop_waves = 256 * 32;             // grid of k_raycast_coop (2 KB of LDS per wave: wave slots limit residency)
+    int quad_waves = 256 * 24;             // grid of k_raycast_quad
     uint2 *coop_spill = nullptr;           // [coop_waves][8][COOP_SPILL]
     int ray_chunk = 256, coop_chunk = 64;  // rays a persistent wave takes from the queue per atomic (big batches)
     int fused_tail = 1;                    // 0 (CHROMA_TAIL=split): the last photons also take one launch set per step
     int split_tail = 1;                    // 0 (CHROMA_TAIL=fused): the last launch of chroma_propagate is the fused kernel
-    int wide_walk = 2;                     // CHROMA_WALK_*: 0 reference tree, 1 wide tree one lane per ray, 2 wide tree 8 lanes per ray
+    int wide_walk = CHROMA_WALK_QUAD;      // CHROMA_WALK_*: reference tree | wide tree with 1, 8 or 4 (default) lanes per ray
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
 };
 
@@ -870,6 +871,250 @@ k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
     }
 }
 
+// ---- the same ray cast with FOUR lanes per ray, two child entries per lane ---------------------------
+// 16 rays per wavefront.  The per-visit bookkeeping of k_raycast_coop (ballots, prefix counts, the
+// reduction that picks the nearest child, the loop control) costs as much as the eight slab tests it
+// serves; here one pass of that bookkeeping serves 16 rays instead of 8, the reductions run inside a
+// quad (two DPP steps), and a lane's two entries are one 32-byte read.  Postponed triangles live in a
+// 16-entry ring per ray and are tested four at a time.  Same tree, same tie-break, same results.
+#define QUAD_STRIDE (2 * COOP_STACK + COOP_PENDING + 1)     // words per ray, +1 staggers the banks
+#ifndef QUAD_REFILL_MIN
+#define QUAD_REFILL_MIN 4    // refill once this many of the 16 rays are done
+#endif
+#ifndef QUAD_WAVES_PER_EU
+#define QUAD_WAVES_PER_EU 7
+#endif
+
+__device__ inline uint32_t quad_min_u32(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+    return v;
+}
+__device__ inline uint32_t quad_max_u32(uint32_t v)
+{
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+    return v;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD_WAVES_PER_EU, QUAD_WAVES_PER_EU))) void
+k_raycast_quad(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
+               int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint2 *spill_base, DeviceCounters *counters,
+               int big_chunk)
+{
+    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    if ((long long)blockIdx.x * 16 >= nthreads) return;
+    uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
+    const int chunk = ((long long)nthreads > 4ll * big_chunk * (long long)gridDim.x) ? big_chunk : 16;
+    static_assert(PROP_BLOCK == WAVE, "one wave per workgroup");
+    static_assert(COOP_PENDING == 16, "the ring of postponed triangles is indexed modulo 16");
+    __shared__ uint32_t s_lds[16 * QUAD_STRIDE];
+    const unsigned lane = lane_id();
+    const unsigned j = lane & 3u, gshift = lane & ~3u, grp = lane >> 2;
+    const uint32_t below = (1u << j) - 1u;
+    uint32_t *stack_n = s_lds + grp * QUAD_STRIDE;
+    float *stack_t = (float *)(stack_n + COOP_STACK);
+    uint32_t *pending = stack_n + 2 * COOP_STACK;
+    uint2 *spill = spill_base + ((size_t)blockIdx.x * 16 + grp) * COOP_SPILL;
+    LaneCounters cnt = {0, 0, 0, 0};
+
+    // per-ray state, identical in the 4 lanes of a quad
+    bool has_ray = false, active = false;
+    int slot = 0;
+    v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
+    RayFast rf;
+    rf.a = rf.blo = rf.bhi = mk3(0.f, 0.f, 0.f);
+    int last_hit = -1, triangle_index = -1;
+    uint32_t best_rank = 0;
+    float min_distance = -1.0f;
+    uint32_t cur = WIDE_NONE;
+    int sp = 0, npend = 0;
+    uint32_t phead = 0;                     // first postponed triangle in the ring
+    uint32_t loc_next = 0, loc_end = 0;
+    bool exhausted = false;
+
+    for (;;) {
+        // ---- refill idle quads
+        unsigned long long idle_mask = __ballot(!has_ray && j == 0);
+        int n_idle = __popcll(idle_mask);
+        bool more = !exhausted || loc_next < loc_end;
+        if (more && (n_idle >= QUAD_REFILL_MIN || n_idle == 16)) {
+            if (loc_next >= loc_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work_counter, (uint32_t)chunk);
+                base = __shfl(base, 0);
+                if (base + (uint32_t)chunk >= (uint32_t)nthreads) exhausted = true;
+                loc_next = min(base, (uint32_t)nthreads);
+                loc_end = min(base + (uint32_t)chunk, (uint32_t)nthreads);
+            }
+            uint32_t idx = loc_next + (uint32_t)__popcll(idle_mask & ((1ull << gshift) - 1ull));
+            loc_next = min(loc_end, loc_next + (uint32_t)n_idle);
+            if (!has_ray && idx < loc_end) {
+                slot = first_photon + (int)idx;
+                uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
+                int result = HIT_SKIP;
+                if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
+                    origin = load3(pv.pos, photon_id);
+                    direction = load3(pv.dir, photon_id);
+                    if (renorm) direction = direction / norm(direction);
+                    if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
+                        result = HIT_NAN;
+                    } else {
+                        v3 noid = (-origin) / direction;
+                        v3 inv_dir = 1.0f / direction;
+                        bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                                        cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+                        if (!moderate) {
+                            result = HIT_RETRY;
+                        } else {
+                            rf = ray_fast(g, noid, inv_dir);
+                            last_hit = pv.last_hit_dev[photon_id];
+                            triangle_index = -1;
+                            min_distance = -1.0f;
+                            sp = 0;
+                            npend = 0;
+                            phead = 0;
+                            cur = 0;
+                            has_ray = true;
+                            active = true;
+                            result = 0;
+                        }
+                    }
+                }
+                if (!has_ray && j == 0) {
+                    hit_triangle[slot] = result;
+                    hit_distance[slot] = 0.0f;
+                    if (result == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
+                }
+            }
+        }
+        if (!__any(has_ray)) {
+            if (exhausted && loc_next >= loc_end) break;
+            continue;
+        }
+
+        // ---- node phase: every active quad visits one node per iteration
+        more = !exhausted || loc_next < loc_end;
+        const int stop_at = more ? max(0, __popcll(__ballot(active && j == 0)) - QUAD_REFILL_MIN) : 0;
+        do {
+            if (active && cur == WIDE_NONE) {
+                while (sp > 0) {
+                    sp--;
+                    uint32_t n; float t;
+                    if (sp < COOP_STACK) { n = stack_n[sp]; t = stack_t[sp]; }
+                    else { uint2 se = spill[sp - COOP_STACK]; n = se.x; t = __uint_as_float(se.y); }
+                    if (min_distance < 0.0f || !(t > min_distance)) { cur = n; break; }
+                }
+                if (cur == WIDE_NONE) active = false;
+            }
+            if (active) {
+                const uint4 *np = g.wnodes + 8 * (size_t)cur + 2 * j;       // this lane's two entries: 32 bytes
+                const uint4 ea = np[0], eb = np[1];
+                if (COUNT && j == 0) cnt.nodes += 8;
+                const float ta = box_tmin_fast(rf, ea), tb = box_tmin_fast(rf, eb);
+                const bool pa = (ea.w != WIDE_NONE) && node_passes(ta, min_distance);
+                const bool pb = (eb.w != WIDE_NONE) && node_passes(tb, min_distance);
+                const bool la = pa && (ea.w & 0x80000000u) && (int)(ea.w & 0x7FFFFFFFu) != last_hit;
+                const bool lb = pb && (eb.w & 0x80000000u) && (int)(eb.w & 0x7FFFFFFFu) != last_hit;
+                const bool ia = pa && !(ea.w & 0x80000000u), ib = pb && !(eb.w & 0x80000000u);
+                const uint32_t mla = (uint32_t)(__ballot(la) >> gshift) & 0xFu, mlb = (uint32_t)(__ballot(lb) >> gshift) & 0xFu;
+                const uint32_t mia = (uint32_t)(__ballot(ia) >> gshift) & 0xFu, mib = (uint32_t)(__ballot(ib) >> gshift) & 0xFu;
+                // postponed triangles: ring slots after the ones already there, lower lanes first
+                {
+                    uint32_t off = phead + (uint32_t)npend + __popc(mla & below) + __popc(mlb & below);
+                    if (la) pending[off & 15u] = ea.w & 0x7FFFFFFFu;
+                    if (lb) pending[(off + (la ? 1u : 0u)) & 15u] = eb.w & 0x7FFFFFFFu;
+                    npend += __popc(mla) + __popc(mlb);
+                }
+                cur = WIDE_NONE;
+                if (mia | mib) {
+                    // nearest inner child: smallest (distance, entry) key -- the entry number replaces
+                    // the low 3 mantissa bits, which only matters for the ORDER of the visits
+                    const uint32_t ka = ia ? ((__float_as_uint(ta) & ~7u) | (2u * j)) : 0xFFFFFFFFu;
+                    const uint32_t kb = ib ? ((__float_as_uint(tb) & ~7u) | (2u * j + 1u)) : 0xFFFFFFFFu;
+                    const uint32_t ne = quad_min_u32(min(ka, kb)) & 7u;          // entry number of the nearest
+                    const bool na = ia && ne == 2u * j, nb = ib && ne == 2u * j + 1u;
+                    cur = quad_max_u32(na ? ea.w : (nb ? eb.w : 0u));
+                    // every other inner child goes on the stack at its own slot
+                    const bool qa = ia && !na, qb = ib && !nb;
+                    const uint32_t moa = mia & ~((ne & 1u) ? 0u : (1u << (ne >> 1)));
+                    const uint32_t mob = mib & ~((ne & 1u) ? (1u << (ne >> 1)) : 0u);
+                    int pos = sp + __popc(moa & below) + __popc(mob & below);
+                    if (qa) {
+                        if (pos < COOP_STACK) { stack_n[pos] = ea.w; stack_t[pos] = ta; }
+                        else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(ea.w, __float_as_uint(ta));
+                        pos++;
+                    }
+                    if (qb) {
+                        if (pos < COOP_STACK) { stack_n[pos] = eb.w; stack_t[pos] = tb; }
+                        else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(eb.w, __float_as_uint(tb));
+                    }
+                    sp += __popc(moa) + __popc(mob);
+                    if (sp > COOP_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
+                        triangle_index = HIT_RETRY;
+                        active = false; npend = 0; cur = WIDE_NONE; sp = 0;
+                    }
+                }
+            }
+        } while (!__any(npend >= 4) && __popcll(__ballot(active && j == 0)) > stop_at);
+        __builtin_amdgcn_wave_barrier();      // (scheduling fence: the lanes of a quad exchange data through LDS)
+
+        // ---- leaf phase: up to 4 postponed triangles of a ray at once, one per lane
+        while (__any(npend > 0)) {
+            if (npend > 0) {
+                const int take = min(npend, 4);
+                bool hit = false;
+                float distance = 0.0f;
+                uint32_t tri = 0, rank = 0xFFFFFFFFu;
+                if ((int)j < take) {
+                    tri = pending[(phead + j) & 15u];
+                    if (COUNT) cnt.tris++;
+                    const float4 *tp = g.tri + 3 * (size_t)tri;
+                    float4 a = tp[0], b = tp[1], c = tp[2];
+                    hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
+                    rank = __float_as_uint(c.w);
+                }
+                // distances are positive: their bit patterns order like the floats
+                const uint32_t dkey = hit ? __float_as_uint(distance) : 0x7F800000u;
+                const uint32_t dmin = quad_min_u32(dkey);
+                if (dmin != 0x7F800000u) {
+                    const float dm = __uint_as_float(dmin);
+                    const bool cand = hit && dkey == dmin;
+                    const uint32_t rm = quad_min_u32(cand ? rank : 0xFFFFFFFFu);
+                    const uint32_t wtri = quad_max_u32((cand && rank == rm) ? tri + 1u : 0u) - 1u;
+                    if (triangle_index == -1 || dm < min_distance || (dm == min_distance && rm < best_rank)) {
+                        triangle_index = (int)wtri;
+                        min_distance = dm;
+                        best_rank = rm;
+                    }
+                }
+                phead = (phead + (uint32_t)take) & 15u;
+                npend -= take;
+            }
+        }
+
+        // ---- retire finished rays
+        if (has_ray && !active) {
+            if (j == 0) {
+                hit_triangle[slot] = triangle_index;                 // record index, or a HIT_* code
+                hit_distance[slot] = min_distance;
+                if (triangle_index == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
+            }
+            has_ray = false;
+        }
+    }
+
+    if (COUNT) {
+        unsigned long long nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        if (lane == 0) {
+            atomicAdd(&counters->nodes_visited, nd);
+            atomicAdd(&counters->triangles_tested, tr);
+        }
+    }
+}
+
 // ---- fused tail: all remaining steps of the last few photons, eight lanes per photon ---------------
 // Once fewer than 64*16*8 photons are alive the reference finishes them in ONE launch
 // (chroma/gpu/photon.py:227-230).  Per-step launches are a poor fit for that tail -- a few thousand
@@ -1573,18 +1818,21 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (need > STACK_LDS + STACK_SCRATCH)
         return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
     const bool have_wide = geom->view.wnodes != nullptr;
-    const bool coop = ctx->wide_walk == CHROMA_WALK_COOP && have_wide && geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
+    const bool quad = ctx->wide_walk == CHROMA_WALK_QUAD && have_wide && geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
+    const bool coop = !quad && (ctx->wide_walk == CHROMA_WALK_COOP || ctx->wide_walk == CHROMA_WALK_QUAD) && have_wide &&
+                      geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
     const bool wide = !coop && ctx->wide_walk != CHROMA_WALK_REFERENCE && have_wide && geom->wide_stack_need <= WIDE_STACK + WIDE_SPILL;
     if (wide && !ctx->wide_spill) {
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipMalloc((void **)&ctx->wide_spill, (size_t)ctx->wide_waves * WIDE_SPILL * PROP_BLOCK * sizeof(uint2)));
     }
-    if (coop && !ctx->coop_spill) {
+    if ((coop || quad) && !ctx->coop_spill) {
         HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, (size_t)ctx->coop_waves * 8 * COOP_SPILL * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, (size_t)ctx->coop_waves * 16 * COOP_SPILL * sizeof(uint2)));
     }
     // persistent ray cast: enough waves to fill the chip, each pulling rays from the queue
-    unsigned waves = coop ? (unsigned)std::min<long long>((n_upper + 7) / 8, (long long)ctx->coop_waves)
+    unsigned waves = quad ? (unsigned)std::min<long long>((n_upper + 15) / 16, (long long)ctx->quad_waves)
+                   : coop ? (unsigned)std::min<long long>((n_upper + 7) / 8, (long long)ctx->coop_waves)
                           : (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK,
                                                           (long long)(wide ? ctx->wide_waves : ctx->persistent_waves));
     dim3 grid(waves), block(PROP_BLOCK);
@@ -1594,7 +1842,10 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (ev) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
 #define RAYCAST_LAUNCH(COUNT)                                                                                          \
     do {                                                                                                               \
-        if (coop)                                                                                                      \
+        if (quad)                                                                                                      \
+            hipLaunchKernelGGL((k_raycast_quad<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,          \
+                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
+        else if (coop)                                                                                                 \
             hipLaunchKernelGGL((k_raycast_coop<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,          \
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
         else if (wide)                                                                                                 \
@@ -1637,7 +1888,7 @@ static int launch_tail(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, lo
         return CHROMA_OK;
     if (!ctx->coop_spill) {
         HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, (size_t)ctx->coop_waves * 8 * COOP_SPILL * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, (size_t)ctx->coop_waves * 16 * COOP_SPILL * sizeof(uint2)));
     }
     unsigned waves = (unsigned)std::min<long long>((n_upper + 7) / 8, (long long)ctx->coop_waves);
     if ((long long)waves * 8 < n_upper) return CHROMA_OK;          // (cannot happen below 8192 photons)
@@ -1748,8 +1999,12 @@ int chroma_init(int device, chroma_ctx **out)
         int coop_per_cu = 28;                // 71 VGPRs (amdgpu_waves_per_eu 7): 7 waves per SIMD
         if (const char *e = getenv("CHROMA_COOP_WAVES_PER_CU")) coop_per_cu = std::max(1, atoi(e));
         ctx->coop_waves = prop.multiProcessorCount * coop_per_cu;
+        int quad_per_cu = 4 * QUAD_WAVES_PER_EU;
+        if (const char *e = getenv("CHROMA_QUAD_WAVES_PER_CU")) quad_per_cu = std::max(1, atoi(e));
+        ctx->quad_waves = std::min(prop.multiProcessorCount * quad_per_cu, ctx->coop_waves);      // (shares the spill area)
         if (const char *e = getenv("CHROMA_WALK"))
-            ctx->wide_walk = !strcmp(e, "reference") ? CHROMA_WALK_REFERENCE : !strcmp(e, "wide") ? CHROMA_WALK_WIDE : CHROMA_WALK_COOP;
+            ctx->wide_walk = !strcmp(e, "reference") ? CHROMA_WALK_REFERENCE : !strcmp(e, "wide") ? CHROMA_WALK_WIDE
+                           : !strcmp(e, "coop") ? CHROMA_WALK_COOP : CHROMA_WALK_QUAD;
         if (const char *e = getenv("CHROMA_RAY_CHUNK")) ctx->ray_chunk = std::max(64, atoi(e));
         if (const char *e = getenv("CHROMA_COOP_CHUNK")) ctx->coop_chunk = std::max(8, atoi(e));
         if (const char *e = getenv("CHROMA_TAIL")) {      // coop (default) | split | fused (the lane-per-photon k_propagate)
@@ -2260,7 +2515,7 @@ int chroma_set_counting(chroma_ctx *ctx, int32_t enabled)
 int chroma_set_walk(chroma_ctx *ctx, int32_t mode)
 {
     if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
-    if (mode != CHROMA_WALK_REFERENCE && mode != CHROMA_WALK_WIDE && mode != CHROMA_WALK_COOP)
+    if (mode != CHROMA_WALK_REFERENCE && mode != CHROMA_WALK_WIDE && mode != CHROMA_WALK_COOP && mode != CHROMA_WALK_QUAD)
         return set_error(CHROMA_ERR_INVALID, "unknown walk mode %d", mode);
     ctx->wide_walk = mode;
     return CHROMA_OK;
@@ -2309,7 +2564,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         int step = 0, next_check = 1, steps_timed = 0;
         bool done = false;
         const long long few = (long long)PROP_BLOCK * 16 * 8;
-        const bool fused_tail = ctx->fused_tail && ctx->wide_walk == CHROMA_WALK_COOP;    // (the cross-check walks keep per-step launches)
+        const bool fused_tail = ctx->fused_tail && (ctx->wide_walk == CHROMA_WALK_COOP || ctx->wide_walk == CHROMA_WALK_QUAD);    // (the cross-check walks keep per-step launches)
         int tail_step = -1;                  // the step at which the fused tail was launched
         while (step < max_steps && !done) {
             if (fused_tail && n_upper < few) {

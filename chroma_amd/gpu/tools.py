@@ -86,8 +86,8 @@ class Context(object):
         _lib.check(self._lib.chroma_set_counting(self.handle, 1 if enabled else 0))
 
     def set_walk(self, mode):
-        """'coop' (default), 'wide' or 'reference': how the per-step ray cast walks (same results)."""
-        _lib.check(self._lib.chroma_set_walk(self.handle, {'reference': 0, 'wide': 1, 'coop': 2}[mode]))
+        """'quad' (default), 'coop', 'wide' or 'reference': how the per-step ray cast walks (same results)."""
+        _lib.check(self._lib.chroma_set_walk(self.handle, {'reference': 0, 'wide': 1, 'coop': 2, 'quad': 3}[mode]))
 
     def read_stats(self):
         stats = _lib.PropagateStats()

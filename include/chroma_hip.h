@@ -327,13 +327,13 @@ int chroma_propagate_stats_read(chroma_ctx *ctx, chroma_propagate_stats *stats);
 int chroma_set_counting(chroma_ctx *ctx, int32_t enabled);
 
 /* Which tree the one-step ray cast walks, and how: the reference-format nodes in the reference's
- * own order, the derived 8-wide tree with one lane per ray, or the 8-wide tree with the eight
- * lanes of a group sharing one ray (default).  Results are identical by construction; the switch
- * exists so that tests and benchmarks can show it.  Env CHROMA_WALK=reference|wide|coop sets the
- * initial mode of a context. */
+ * own order, or the derived 8-wide tree with one, eight or four (default) lanes sharing a ray.
+ * Results are identical by construction; the switch exists so that tests and benchmarks can show
+ * it.  Env CHROMA_WALK=reference|wide|coop|quad sets the initial mode of a context. */
 #define CHROMA_WALK_REFERENCE 0
 #define CHROMA_WALK_WIDE      1
 #define CHROMA_WALK_COOP      2
+#define CHROMA_WALK_QUAD      3   /* the wide tree with four lanes per ray, two child entries per lane */
 int chroma_set_walk(chroma_ctx *ctx, int32_t mode);
 
 #ifdef __cplusplus

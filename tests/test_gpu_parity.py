@@ -78,7 +78,7 @@ def test_large_batch_uses_per_step_launches(gpu, oracle_mod, tiny_geometry):
     assert stats['triangles_tested'] <= 1.3 * ostats['triangles_tested']
     # the same batch with the other two ray casts -- one lane per ray over the wide tree, and the
     # reference tree in the reference's order: identical results
-    for mode in ('wide', 'reference'):
+    for mode in ('coop', 'wide', 'reference'):
         gpu.get_context().set_walk(mode)
         try:
             gp2 = gpu.GPUPhotons(ph)
@@ -87,7 +87,7 @@ def test_large_batch_uses_per_step_launches(gpu, oracle_mod, tiny_geometry):
             gp2.propagate(gg, gpu.get_rng_states(64 * 1024, seed=12345), max_steps=30, stats=stats2)
             gpu.get_context().set_counting(False)
         finally:
-            gpu.get_context().set_walk('coop')
+            gpu.get_context().set_walk('quad')
         assert_bit_exact(gp2.get(), want, 'tiny 60k, %s walk' % mode)
         assert stats2['photon_steps'] == ostats['photon_steps']
         if mode == 'reference':
@@ -447,13 +447,13 @@ def test_exact_ties_follow_the_reference_test_order(gpu, oracle_mod, tiny_geomet
     from chroma_amd.gpu.geometry import pack_geometry
     dist, tri, _ = oracle_mod.distance_to_mesh(pack_geometry(tiny_geometry), ph.pos[:4000], ph.dir[:4000])
     assert (tri >= 0).mean() > 0.9
-    for mode in ('wide', 'reference'):
+    for mode in ('coop', 'wide', 'reference'):
         gpu.get_context().set_walk(mode)
         try:
             gp2 = gpu.GPUPhotons(ph)
             gp2.propagate(gg, gpu.get_rng_states(64 * 1024, seed=12345), max_steps=4)
         finally:
-            gpu.get_context().set_walk('coop')
+            gpu.get_context().set_walk('quad')
         assert_bit_exact(gp2.get(), want, 'aimed rays, %s walk' % mode)
 
 

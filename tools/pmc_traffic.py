@@ -4,11 +4,11 @@ HBM bytes = 2 * FETCH_SIZE(KB) * 1024 + WRITE_SIZE(KB) * 1024.  The factor 2 on 
 correction of MI355X_MICROARCH.md (requests of 128 B tallied at 64 B), re-calibrated for THIS access pattern
 with tools/calib_fetch.hip: 268 M scattered 16-B reads report 64 B each while running at the 128-B-line rate of
 the streaming peak (6.3 TB/s), and a 4 GiB coalesced stream reports 2 GiB.  WRITE_SIZE is taken as is.
-usage: pmc_traffic.py FETCH_DIR WRITE_DIR key [kernel-name-substring, default k_raycast_coop]
+usage: pmc_traffic.py FETCH_DIR WRITE_DIR key [kernel-name-substring, default k_raycast_quad]
 """
 import csv, glob, json, os, sys
 fetch_dir, write_dir, key = sys.argv[1:4]
-kernel = sys.argv[4] if len(sys.argv) > 4 else 'k_raycast_coop'
+kernel = sys.argv[4] if len(sys.argv) > 4 else 'k_raycast_quad'
 def total(d, counter, name):
     tot, n = 0.0, 0
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
