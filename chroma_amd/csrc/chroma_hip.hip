@@ -876,13 +876,19 @@ k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
 // reduction that picks the nearest child, the loop control) costs as much as the eight slab tests it
 // serves; here one pass of that bookkeeping serves 16 rays instead of 8, the reductions run inside a
 // quad (two DPP steps), and a lane's two entries are one 32-byte read.  Postponed triangles live in a
-// 16-entry ring per ray and are tested four at a time.  Same tree, same tie-break, same results.
-#define QUAD_STRIDE (2 * COOP_STACK + COOP_PENDING + 1)     // words per ray, +1 staggers the banks
+// ring per ray and are tested four at a time.  Same tree, same tie-break, same results.
+#ifndef QUAD_PENDING
+#define QUAD_PENDING 16      // ring of postponed triangles per ray (a power of two; 32 costs residency, measured slower)
+#endif
+#define QUAD_STRIDE (2 * COOP_STACK + QUAD_PENDING + 1)     // words per ray, +1 staggers the banks
 #ifndef QUAD_REFILL_MIN
 #define QUAD_REFILL_MIN 4    // refill once this many of the 16 rays are done
 #endif
 #ifndef QUAD_WAVES_PER_EU
 #define QUAD_WAVES_PER_EU 7
+#endif
+#ifndef QUAD_FLUSH
+#define QUAD_FLUSH 8         // run the triangle tests once a ray has this many postponed (a visit adds up to 8)
 #endif
 
 __device__ inline uint32_t quad_min_u32(uint32_t v)
@@ -909,7 +915,7 @@ k_raycast_quad(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
     uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
     const int chunk = ((long long)nthreads > 4ll * big_chunk * (long long)gridDim.x) ? big_chunk : 16;
     static_assert(PROP_BLOCK == WAVE, "one wave per workgroup");
-    static_assert(COOP_PENDING == 16, "the ring of postponed triangles is indexed modulo 16");
+    static_assert((QUAD_PENDING & (QUAD_PENDING - 1)) == 0 && QUAD_FLUSH - 1 + 8 <= QUAD_PENDING, "ring of postponed triangles");
     __shared__ uint32_t s_lds[16 * QUAD_STRIDE];
     const unsigned lane = lane_id();
     const unsigned j = lane & 3u, gshift = lane & ~3u, grp = lane >> 2;
@@ -1024,8 +1030,8 @@ k_raycast_quad(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                 // postponed triangles: ring slots after the ones already there, lower lanes first
                 {
                     uint32_t off = phead + (uint32_t)npend + __popc(mla & below) + __popc(mlb & below);
-                    if (la) pending[off & 15u] = ea.w & 0x7FFFFFFFu;
-                    if (lb) pending[(off + (la ? 1u : 0u)) & 15u] = eb.w & 0x7FFFFFFFu;
+                    if (la) pending[off & (QUAD_PENDING - 1u)] = ea.w & 0x7FFFFFFFu;
+                    if (lb) pending[(off + (la ? 1u : 0u)) & (QUAD_PENDING - 1u)] = eb.w & 0x7FFFFFFFu;
                     npend += __popc(mla) + __popc(mlb);
                 }
                 cur = WIDE_NONE;
@@ -1058,7 +1064,7 @@ k_raycast_quad(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                     }
                 }
             }
-        } while (!__any(npend >= 4) && __popcll(__ballot(active && j == 0)) > stop_at);
+        } while (!__any(npend >= QUAD_FLUSH) && __popcll(__ballot(active && j == 0)) > stop_at);
         __builtin_amdgcn_wave_barrier();      // (scheduling fence: the lanes of a quad exchange data through LDS)
 
         // ---- leaf phase: up to 4 postponed triangles of a ray at once, one per lane
@@ -1069,7 +1075,7 @@ k_raycast_quad(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                 float distance = 0.0f;
                 uint32_t tri = 0, rank = 0xFFFFFFFFu;
                 if ((int)j < take) {
-                    tri = pending[(phead + j) & 15u];
+                    tri = pending[(phead + j) & (QUAD_PENDING - 1u)];
                     if (COUNT) cnt.tris++;
                     const float4 *tp = g.tri + 3 * (size_t)tri;
                     float4 a = tp[0], b = tp[1], c = tp[2];
@@ -1090,7 +1096,7 @@ k_raycast_quad(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
                         best_rank = rm;
                     }
                 }
-                phead = (phead + (uint32_t)take) & 15u;
+                phead = (phead + (uint32_t)take) & (QUAD_PENDING - 1u);
                 npend -= take;
             }
         }
