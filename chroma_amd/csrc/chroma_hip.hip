@@ -1399,7 +1399,10 @@ k_raycast_retry(GeoView g, PhotonView pv, int first_photon, const StepState *st,
 }
 
 #define PHYS_BLOCK 512
-__global__ __launch_bounds__(PHYS_BLOCK) void
+#ifndef PHYS_WAVES_PER_EU
+#define PHYS_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(PHYS_BLOCK) __attribute__((amdgpu_waves_per_eu(PHYS_WAVES_PER_EU))) void
 k_physics(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue, uint32_t *output_queue,
           const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base, int use_weights,
           int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters)

@@ -178,19 +178,19 @@ __device__ inline bool record_hit_is_regular(const GeoView &g, float4 a, float4 
 
 // the leaf box of a triangle by the reference's rule (cuda/bvh.cu:149-203: truncate, one quantum down,
 // one up), for the lane-per-ray kernels, which do not carry the box of a postponed triangle
+__device__ inline uint32_t leaf_word(float lo, float hi, float org, float ws)
+{
+    uint32_t ql = (uint32_t)((lo - org) / ws);
+    if (ql > 0) ql--;
+    uint32_t qu = (uint32_t)((hi - org) / ws) + 1u;
+    return ql | qu << 16;
+}
 __device__ inline void leaf_words(const GeoView &g, v3 v0, v3 v1, v3 v2, uint32_t &bx, uint32_t &by, uint32_t &bz)
 {
     const float ws = g.world_scale;
-    float lo[3] = {fminf(fminf(v0.x, v1.x), v2.x), fminf(fminf(v0.y, v1.y), v2.y), fminf(fminf(v0.z, v1.z), v2.z)};
-    float hi[3] = {fmaxf(fmaxf(v0.x, v1.x), v2.x), fmaxf(fmaxf(v0.y, v1.y), v2.y), fmaxf(fmaxf(v0.z, v1.z), v2.z)};
-    uint32_t w[3];
-    for (int k = 0; k < 3; k++) {
-        uint32_t ql = (uint32_t)((lo[k] - g.world_origin[k]) / ws);
-        if (ql > 0) ql--;
-        uint32_t qu = (uint32_t)((hi[k] - g.world_origin[k]) / ws) + 1u;
-        w[k] = ql | qu << 16;
-    }
-    bx = w[0]; by = w[1]; bz = w[2];
+    bx = leaf_word(fminf(fminf(v0.x, v1.x), v2.x), fmaxf(fmaxf(v0.x, v1.x), v2.x), g.world_origin[0], ws);
+    by = leaf_word(fminf(fminf(v0.y, v1.y), v2.y), fmaxf(fmaxf(v0.y, v1.y), v2.y), g.world_origin[1], ws);
+    bz = leaf_word(fminf(fminf(v0.z, v1.z), v2.z), fmaxf(fmaxf(v0.z, v1.z), v2.z), g.world_origin[2], ws);
 }
 
 // pruning rule of intersect_node (mesh.h:16-34) given the box distance
