@@ -192,10 +192,10 @@ def main():
     path_achieved = (bytes_per_photon * nphotons * args.steps) / kernel_s / 1e9 if kernel_s > 0 else 0.0
     # dominant kernel: the ray cast (k_raycast_quad; the retry pass after it is normally empty).
     # Algorithmic bytes per photon step: 16 B per child entry fetched (a 128-B wide node = 8 entries)
-    # + 48 B per triangle tested + 36 B ray state read + 8 B hit written
+    # + 48 B per triangle tested + 64 B ray record read + 8 B hit written
     ray_s = stats['raycast_ms'] / 1e3
     ray_launches = max(1, stats['raycast_launches'])
-    ray_bytes_per_step = 16.0 * nodes_ps + 48.0 * tris_ps + 36 + 8
+    ray_bytes_per_step = 16.0 * nodes_ps + 48.0 * tris_ps + 64 + 8
     ray_bytes_total = ray_bytes_per_step * steps_pp * nphotons * args.steps
     achieved = ray_bytes_total / ray_s / 1e9 if ray_s > 0 else 0.0
     log('timed: %.3f s for %d steps; propagate kernels %.3f s in %d launches, of which ray cast %.3f s in %d launches '

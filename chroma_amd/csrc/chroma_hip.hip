@@ -60,6 +60,7 @@ struct chroma_ctx {
     float *hit_distance = nullptr;
     int32_t *last_hit_dev = nullptr;       // [capacity] last_hit_triangles as record indices (PhotonView::last_hit_dev)
     uint32_t *retry_list = nullptr;        // [capacity] queue slots handed to k_raycast_retry
+    float4 *rays = nullptr;                // [capacity][4] ray records (k_ray_setup)
     // small device scratch: [0..3] DeviceCounters, then misc words
     DeviceCounters *d_counters = nullptr;
     uint32_t *d_words = nullptr;        // 16 words
@@ -68,7 +69,7 @@ struct chroma_ctx {
     StepState *d_step = nullptr;           // device-side step control block (k_step_begin)
     uint32_t *h_step = nullptr;            // pinned copy for the occasional read-back
     int physics_blocks = 256 * 8;          // grid cap of k_physics (blocks stride over the queue)
-    std::vector<hipEvent_t> step_events;   // 3 per step when kernels are timed
+    std::vector<hipEvent_t> step_events;   // 4 per step when kernels are timed
     int persistent_waves = 256 * 20 * 4;   // grid of the persistent ray-cast kernel (set from the device at init)
     int wide_waves = 256 * 14;             // same for k_raycast_wide (11 KB of LDS per wave)
     uint2 *wide_spill = nullptr;           // [wide_waves][WIDE_SPILL][64] stack entries beyond the LDS part
@@ -204,6 +205,7 @@ k_propagate(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint
 // propagate.cu:248,250 when the step opens a launch in the reference's sense, see k_step_begin).
 #define HIT_SKIP (-3)      // photon already terminal: untouched (propagate.cu:258)
 #define HIT_NAN  (-2)      // NaN guard fired (propagate.cu:270-273)
+#define HIT_RETRY (-4)     // the ray takes the literal reference walk (k_raycast_retry)
 
 // ---- device-side step control ---------------------------------------------------------------------
 // chroma_propagate enqueues its steps without waiting for any of them: how many photons a step has
@@ -224,6 +226,61 @@ __global__ void k_step_begin(const uint32_t *in_queue, uint32_t *out_queue, Step
     out_queue[0] = 1u;
 }
 
+// ---- ray records --------------------------------------------------------------------------------------
+// What a ray cast needs of a photon, prepared once per step by a streaming kernel instead of inside the
+// persistent ray-cast kernels: there the set-up of a new ray (two dependent gathers, a normalisation,
+// six IEEE divisions for the slab constants, the NaN and "moderate" checks) was ~300 instructions
+// executed by the whole wave for the few rays being refilled -- a quarter of the kernel's VALU work.
+// A record is 64 bytes at the queue slot: {origin, last hit record}, {direction, status},
+// {a = scale/d}, {b = (world_origin - o)/d} (RayFast: blo = b - a, bhi = b + a).  Status 0 = cast; the
+// other slots (terminal photon, NaN, 1/d not moderate) get their hit entry -- and their place in the
+// retry list -- right here.
+__global__ __launch_bounds__(256) void
+k_ray_setup(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input_queue, float4 *rays,
+            int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint32_t *retry_counter)
+{
+    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < nthreads; slot += gridDim.x * blockDim.x) {
+        uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
+        int status = HIT_SKIP;
+        v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f), a = mk3(0.f, 0.f, 0.f), b = mk3(0.f, 0.f, 0.f);
+        int last_hit = -1;
+        if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
+            origin = load3(pv.pos, photon_id);
+            direction = load3(pv.dir, photon_id);
+            if (renorm) direction = direction / norm(direction);
+            if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
+                status = HIT_NAN;
+            } else {
+                v3 noid = (-origin) / direction;
+                v3 inv_dir = 1.0f / direction;
+                bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                                cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+                if (!moderate) {
+                    status = HIT_RETRY;
+                } else {
+                    a = ray_fast(g, noid, inv_dir).a;
+                    // b exactly as ray_fast forms it (blo = b - a, bhi = b + a are rebuilt by the kernels)
+                    b = mk3(cm_fmaf(g.world_origin[0], inv_dir.x, noid.x), cm_fmaf(g.world_origin[1], inv_dir.y, noid.y),
+                            cm_fmaf(g.world_origin[2], inv_dir.z, noid.z));
+                    last_hit = pv.last_hit_dev[photon_id];
+                    status = 0;
+                }
+            }
+        }
+        float4 *r = rays + 4 * (size_t)slot;
+        r[0] = make_float4(origin.x, origin.y, origin.z, __int_as_float(last_hit));
+        r[1] = make_float4(direction.x, direction.y, direction.z, __int_as_float(status));
+        r[2] = make_float4(a.x, a.y, a.z, 0.0f);
+        r[3] = make_float4(b.x, b.y, b.z, 0.0f);
+        if (status != 0) {
+            hit_triangle[slot] = status;
+            hit_distance[slot] = 0.0f;
+            if (status == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
+        }
+    }
+}
+
 // ---- persistent ray cast with lane refill ---------------------------------------------------------
 // One ray per lane, but a lane that finishes its ray takes the next one from the queue (one atomic
 // per wave per refill), so the 64 lanes of a wave stay busy although their rays need very
@@ -232,7 +289,6 @@ __global__ void k_step_begin(const uint32_t *in_queue, uint32_t *out_queue, Step
 // lives in LDS only.  The rare rays this kernel cannot take -- a component of 1/d that is not
 // "moderate" (exactly or nearly axis-parallel) or a stack deeper than RAY_LDS_STACK -- are marked
 // HIT_RETRY and done by k_raycast_retry with the general code.
-#define HIT_RETRY (-4)
 #ifndef RAY_LDS_STACK
 #define RAY_LDS_STACK 24
 #endif
@@ -670,11 +726,11 @@ __device__ inline uint32_t group8_min_u32(uint32_t v)
 #endif
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(COOP_WAVES_PER_EU, COOP_WAVES_PER_EU))) void
-k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
+k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
                int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint2 *spill_base, DeviceCounters *counters,
                int big_chunk)
 {
-    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    const int nthreads = (int)st->n;
     if ((long long)blockIdx.x * 8 >= nthreads) return;
     uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
     const int chunk = ((long long)nthreads > 4ll * big_chunk * (long long)gridDim.x) ? big_chunk : 8;
@@ -723,39 +779,24 @@ k_raycast_coop(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
             loc_next = min(loc_end, loc_next + (uint32_t)n_idle);
             if (!has_ray && idx < loc_end) {
                 slot = first_photon + (int)idx;
-                uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
-                int result = HIT_SKIP;
-                if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
-                    origin = load3(pv.pos, photon_id);
-                    direction = load3(pv.dir, photon_id);
-                    if (renorm) direction = direction / norm(direction);
-                    if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
-                        result = HIT_NAN;
-                    } else {
-                        v3 noid = (-origin) / direction;
-                        v3 inv_dir = 1.0f / direction;
-                        bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
-                                        cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
-                        if (!moderate) {
-                            result = HIT_RETRY;
-                        } else {
-                            rf = ray_fast(g, noid, inv_dir);
-                            last_hit = pv.last_hit_dev[photon_id];
-                            triangle_index = -1;
-                            min_distance = -1.0f;
-                            sp = 0;
-                            npend = 0;
-                            cur = 0;
-                            has_ray = true;
-                            active = true;
-                            result = 0;
-                        }
-                    }
-                }
-                if (!has_ray && j == 0) {
-                    hit_triangle[slot] = result;
-                    hit_distance[slot] = 0.0f;
-                    if (result == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
+                const float4 *r = rays + 4 * (size_t)slot;
+                const float4 r0 = r[0], r1 = r[1];
+                if (__float_as_int(r1.w) == 0) {                 // (other slots were settled by k_ray_setup)
+                    const float4 r2 = r[2], r3 = r[3];
+                    origin = mk3(r0.x, r0.y, r0.z);
+                    direction = mk3(r1.x, r1.y, r1.z);
+                    last_hit = __float_as_int(r0.w);
+                    rf.a = mk3(r2.x, r2.y, r2.z);
+                    const v3 bb = mk3(r3.x, r3.y, r3.z);
+                    rf.blo = bb - rf.a;
+                    rf.bhi = bb + rf.a;
+                    triangle_index = -1;
+                    min_distance = -1.0f;
+                    sp = 0;
+                    npend = 0;
+                    cur = 0;
+                    has_ray = true;
+                    active = true;
                 }
             }
         }
@@ -906,11 +947,11 @@ __device__ inline uint32_t quad_max_u32(uint32_t v)
 
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD_WAVES_PER_EU, QUAD_WAVES_PER_EU))) void
-k_raycast_quad(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
+k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint2 *spill_base, DeviceCounters *counters,
                int big_chunk)
 {
-    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    const int nthreads = (int)st->n;
     if ((long long)blockIdx.x * 16 >= nthreads) return;
     uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
     const int chunk = ((long long)nthreads > 4ll * big_chunk * (long long)gridDim.x) ? big_chunk : 16;
@@ -959,40 +1000,25 @@ k_raycast_quad(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
             loc_next = min(loc_end, loc_next + (uint32_t)n_idle);
             if (!has_ray && idx < loc_end) {
                 slot = first_photon + (int)idx;
-                uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
-                int result = HIT_SKIP;
-                if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
-                    origin = load3(pv.pos, photon_id);
-                    direction = load3(pv.dir, photon_id);
-                    if (renorm) direction = direction / norm(direction);
-                    if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
-                        result = HIT_NAN;
-                    } else {
-                        v3 noid = (-origin) / direction;
-                        v3 inv_dir = 1.0f / direction;
-                        bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
-                                        cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
-                        if (!moderate) {
-                            result = HIT_RETRY;
-                        } else {
-                            rf = ray_fast(g, noid, inv_dir);
-                            last_hit = pv.last_hit_dev[photon_id];
-                            triangle_index = -1;
-                            min_distance = -1.0f;
-                            sp = 0;
-                            npend = 0;
-                            phead = 0;
-                            cur = 0;
-                            has_ray = true;
-                            active = true;
-                            result = 0;
-                        }
-                    }
-                }
-                if (!has_ray && j == 0) {
-                    hit_triangle[slot] = result;
-                    hit_distance[slot] = 0.0f;
-                    if (result == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
+                const float4 *r = rays + 4 * (size_t)slot;
+                const float4 r0 = r[0], r1 = r[1];
+                if (__float_as_int(r1.w) == 0) {                 // (other slots were settled by k_ray_setup)
+                    const float4 r2 = r[2], r3 = r[3];
+                    origin = mk3(r0.x, r0.y, r0.z);
+                    direction = mk3(r1.x, r1.y, r1.z);
+                    last_hit = __float_as_int(r0.w);
+                    rf.a = mk3(r2.x, r2.y, r2.z);
+                    const v3 bb = mk3(r3.x, r3.y, r3.z);
+                    rf.blo = bb - rf.a;
+                    rf.bhi = bb + rf.a;
+                    triangle_index = -1;
+                    min_distance = -1.0f;
+                    sp = 0;
+                    npend = 0;
+                    phead = 0;
+                    cur = 0;
+                    has_ray = true;
+                    active = true;
                 }
             }
         }
@@ -1818,7 +1844,8 @@ static int launch_propagate(chroma_ctx *ctx, chroma_geometry *geom, PhotonView p
 // one step for many photons: ray cast and physics as two launches
 // One step as ray cast + retry pass + physics, all reading the photon count and the launch policy
 // from ctx->d_step (k_step_begin).  `n_upper` bounds the count and sizes the grids; `in_q`/`out_q`
-// are whole queues (slot 0 = tail).  With `ev` the three events bracket the ray cast and the step.
+// are whole queues (slot 0 = tail).  With `ev` (4 events): [0] step start, [3] ray-cast kernel start,
+// [1] its end, [2] step end.
 static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, long long n_upper, const uint32_t *in_q,
                              uint32_t *out_q, chroma_rng rng, int use_weights, int scatter_first, hipEvent_t *ev = nullptr)
 {
@@ -1849,13 +1876,19 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     const uint32_t *q = in_q + 1;
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st, (uint32_t)(PROP_BLOCK * 16 * 8));
     if (ev) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+    if (quad || coop) {
+        unsigned sblocks = (unsigned)std::min<long long>((n_upper + 255) / 256, (long long)ctx->physics_blocks * 4);
+        hipLaunchKernelGGL(k_ray_setup, dim3(sblocks), dim3(256), 0, ctx->stream, geom->view, pv, st, q, ctx->rays,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, &st->retry);
+    }
+    if (ev) HIP_TRY(hipEventRecord(ev[3], ctx->stream));        // the ray-cast kernel proper is timed from here
 #define RAYCAST_LAUNCH(COUNT)                                                                                          \
     do {                                                                                                               \
         if (quad)                                                                                                      \
-            hipLaunchKernelGGL((k_raycast_quad<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,          \
+            hipLaunchKernelGGL((k_raycast_quad<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
         else if (coop)                                                                                                 \
-            hipLaunchKernelGGL((k_raycast_coop<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,          \
+            hipLaunchKernelGGL((k_raycast_coop<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
         else if (wide)                                                                                                 \
             hipLaunchKernelGGL((k_raycast_wide<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,          \
@@ -2044,6 +2077,7 @@ int chroma_shutdown(chroma_ctx *ctx)
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
     if (ctx->last_hit_dev) hipFree(ctx->last_hit_dev);
     if (ctx->retry_list) hipFree(ctx->retry_list);
+    if (ctx->rays) hipFree(ctx->rays);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_words);
     hipHostFree(ctx->h_words);
@@ -2487,8 +2521,10 @@ static int ensure_queues(chroma_ctx *ctx, size_t n)
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
     if (ctx->last_hit_dev) hipFree(ctx->last_hit_dev);
     if (ctx->retry_list) hipFree(ctx->retry_list);
+    if (ctx->rays) hipFree(ctx->rays);
     ctx->queue_a = ctx->queue_b = nullptr;
     ctx->hit_triangle = nullptr; ctx->hit_distance = nullptr; ctx->last_hit_dev = nullptr; ctx->retry_list = nullptr;
+    ctx->rays = nullptr;
     ctx->queue_capacity = 0;
     HIP_TRY(hipMalloc((void **)&ctx->queue_a, (n + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->queue_b, (n + 1) * sizeof(uint32_t)));
@@ -2496,6 +2532,7 @@ static int ensure_queues(chroma_ctx *ctx, size_t n)
     HIP_TRY(hipMalloc((void **)&ctx->hit_distance, (n + 1) * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&ctx->last_hit_dev, (n + 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->retry_list, (n + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->rays, (n + 1) * 4 * sizeof(float4)));
     ctx->queue_capacity = n + 1;
     return CHROMA_OK;
 }
@@ -2567,7 +2604,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     const bool device_steps = !use_weights && ctx->split_tail;
     if (device_steps) {
         HIP_TRY(hipMemsetAsync(ctx->d_step, 0, sizeof(StepState), ctx->stream));
-        const int nev = time_kernels ? 3 * max_steps : 0;
+        const int nev = time_kernels ? 4 * max_steps : 0;
         while ((int)ctx->step_events.size() < nev) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->step_events.push_back(e); }
         long long n_upper = (long long)nphotons;
         int step = 0, next_check = 1, steps_timed = 0;
@@ -2580,7 +2617,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                 // the reference's last launch: all remaining steps at once, 8 lanes per photon
                 bool launched = false;
                 rc = launch_tail(ctx, geom, pv, n_upper, in_q, out_q, rng, max_steps - step, step == 0 ? scatter_first : 0,
-                                 time_kernels ? ctx->step_events.data() + 3 * step : nullptr, &launched);
+                                 time_kernels ? ctx->step_events.data() + 4 * step : nullptr, &launched);
                 if (rc) return rc;
                 if (launched) {
                     if (time_kernels) { tail_step = step; steps_timed = step + 1; }
@@ -2589,7 +2626,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                 }
             }
             rc = launch_split_step(ctx, geom, pv, n_upper, in_q, out_q, rng, 0, step == 0 ? scatter_first : 0,
-                                   time_kernels ? ctx->step_events.data() + 3 * step : nullptr);
+                                   time_kernels ? ctx->step_events.data() + 4 * step : nullptr);
             if (rc) return rc;
             if (time_kernels) steps_timed = step + 1;
             step++;
@@ -2609,10 +2646,10 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         launches = ((const StepState *)ctx->h_step)->launches;
         for (int k = 0; k < steps_timed; k++) {
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[3 * k], ctx->step_events[3 * k + 2]));
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[4 * k], ctx->step_events[4 * k + 2]));
             kernel_ms += ms;
             if (k == tail_step) continue;             // the fused tail is not a ray-cast launch
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[3 * k], ctx->step_events[3 * k + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[4 * k + 3], ctx->step_events[4 * k + 1]));
             raycast_ms += ms;
             raycast_launches++;
         }
