@@ -50,8 +50,19 @@ __device__ inline float interp_property(const GeoView &g, float x, const float *
 __device__ inline const float *row(const float *tab, const GeoView &g, int idx) { return tab + (size_t)idx * g.wavelength_n; }
 
 // ---- intersect.h --------------------------------------------------------------------------
-// intersect_triangle (intersect.h:26-95): Moeller-Trumbore, f = 1.0/a and the epsilon
-// comparisons in double precision as in the reference.
+// intersect_triangle (intersect.h:26-95): Moeller-Trumbore.  The reference forms f = (float)(1.0 /
+// (double)a); that equals the correctly rounded float quotient 1.0f / a for every float a (the double
+// quotient 2^k/m of a 24-bit m is at least ~2^-49 relative away from any float rounding boundary, far
+// more than the 2^-53 the first rounding can move it, so the second rounding decides alike; checked
+// exhaustively over the mantissas of six exponents incl. denormal results and on 1.2e8 random floats),
+// and the engine is built with correctly rounded float division -- so it divides in float.
+// The reference's epsilon comparisons promote a float to double and compare with
+// -1e-6, 1+1e-6 and 1e-6; for a FLOAT x, "x < c" with a double c equals "x < (smallest float >= c)" and
+// "x > c" equals "x > (largest float <= c)", so they are done in float against those three constants
+// (exactly the same decisions, no conversions; the oracle keeps the reference's form).
+#define MT_NEG_EPS  __uint_as_float(0xB58637BDu)    // smallest float >= -1e-6
+#define MT_ONE_EPS  __uint_as_float(0x3F800008u)    // largest float <= 1 + 1e-6
+#define MT_POS_EPS  __uint_as_float(0x358637BDu)    // largest float <= 1e-6
 __device__ inline bool intersect_triangle(v3 origin, v3 direction, v3 v0, v3 v1, v3 v2, float &distance)
 {
     v3 edge1 = v1 - v0;
@@ -59,15 +70,15 @@ __device__ inline bool intersect_triangle(v3 origin, v3 direction, v3 v0, v3 v1,
     v3 h = cross(direction, edge2);
     float a = dot(edge1, h);
     if (a > -FLT_EPSILON && a < FLT_EPSILON) return false;
-    float f = (float)(1.0 / (double)a);
+    float f = 1.0f / a;
     v3 s = origin - v0;
     float u = f * dot(s, h);
-    if ((double)u < -CHROMA_EPSILON || (double)u > 1.0 + CHROMA_EPSILON) return false;
+    if (u < MT_NEG_EPS || u > MT_ONE_EPS) return false;
     v3 q = cross(s, edge1);
     float v = f * dot(direction, q);
-    if ((double)v < -CHROMA_EPSILON || (double)(u + v) > 1.0 + CHROMA_EPSILON) return false;
+    if (v < MT_NEG_EPS || (u + v) > MT_ONE_EPS) return false;
     float t = f * dot(edge2, q);
-    if ((double)t > CHROMA_EPSILON && t < cm_inff()) {
+    if (t > MT_POS_EPS && t < cm_inff()) {
         distance = t;
         return true;
     }
