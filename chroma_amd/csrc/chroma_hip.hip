@@ -961,6 +961,9 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     const unsigned lane = lane_id();
     const unsigned j = lane & 3u, gshift = lane & ~3u, grp = lane >> 2;
     const uint32_t below = (1u << j) - 1u;
+    // this quad's 4 bits of a 64-bit ballot, without a 64-bit shift (quarter rate): pick the half, extract
+    const uint32_t upper_mask = lane >= 32u ? 0xFFFFFFFFu : 0u, bshift = gshift & 31u;
+#define QUAD_BITS(m) __builtin_amdgcn_ubfe((((uint32_t)((m) >> 32)) & upper_mask) | (((uint32_t)(m)) & ~upper_mask), bshift, 4u)
     uint32_t *stack_n = s_lds + grp * QUAD_STRIDE;
     float *stack_t = (float *)(stack_n + COOP_STACK);
     uint32_t *pending = stack_n + 2 * COOP_STACK;
@@ -973,9 +976,11 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
     RayFast rf;
     rf.a = rf.blo = rf.bhi = mk3(0.f, 0.f, 0.f);
-    int last_hit = -1, triangle_index = -1;
+    uint32_t last_hit_w = WIDE_NONE;        // the leaf word of the photon's last hit (never entered)
+    int triangle_index = -1;
     uint32_t best_rank = 0;
     float min_distance = -1.0f;
+    float prune_t = cm_inff();              // min_distance, or +inf while nothing was hit
     uint32_t cur = WIDE_NONE;
     int sp = 0, npend = 0;
     uint32_t phead = 0;                     // first postponed triangle in the ring
@@ -1006,13 +1011,14 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     const float4 r2 = r[2], r3 = r[3];
                     origin = mk3(r0.x, r0.y, r0.z);
                     direction = mk3(r1.x, r1.y, r1.z);
-                    last_hit = __float_as_int(r0.w);
+                    { const int lh = __float_as_int(r0.w); last_hit_w = lh >= 0 ? (0x80000000u | (uint32_t)lh) : WIDE_NONE; }
                     rf.a = mk3(r2.x, r2.y, r2.z);
                     const v3 bb = mk3(r3.x, r3.y, r3.z);
                     rf.blo = bb - rf.a;
                     rf.bhi = bb + rf.a;
                     triangle_index = -1;
                     min_distance = -1.0f;
+                    prune_t = cm_inff();
                     sp = 0;
                     npend = 0;
                     phead = 0;
@@ -1037,7 +1043,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     uint32_t n; float t;
                     if (sp < COOP_STACK) { n = stack_n[sp]; t = stack_t[sp]; }
                     else { uint2 se = spill[sp - COOP_STACK]; n = se.x; t = __uint_as_float(se.y); }
-                    if (min_distance < 0.0f || !(t > min_distance)) { cur = n; break; }
+                    if (!(t > prune_t)) { cur = n; break; }
                 }
                 if (cur == WIDE_NONE) active = false;
             }
@@ -1045,14 +1051,17 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 const uint4 *np = g.wnodes + 8 * (size_t)cur + 2 * j;       // this lane's two entries: 32 bytes
                 const uint4 ea = np[0], eb = np[1];
                 if (COUNT && j == 0) cnt.nodes += 8;
-                const float ta = box_tmin_fast(rf, ea), tb = box_tmin_fast(rf, eb);
-                const bool pa = (ea.w != WIDE_NONE) && node_passes(ta, min_distance);
-                const bool pb = (eb.w != WIDE_NONE) && node_passes(tb, min_distance);
-                const bool la = pa && (ea.w & 0x80000000u) && (int)(ea.w & 0x7FFFFFFFu) != last_hit;
-                const bool lb = pb && (eb.w & 0x80000000u) && (int)(eb.w & 0x7FFFFFFFu) != last_hit;
-                const bool ia = pa && !(ea.w & 0x80000000u), ib = pb && !(eb.w & 0x80000000u);
-                const uint32_t mla = (uint32_t)(__ballot(la) >> gshift) & 0xFu, mlb = (uint32_t)(__ballot(lb) >> gshift) & 0xFu;
-                const uint32_t mia = (uint32_t)(__ballot(ia) >> gshift) & 0xFu, mib = (uint32_t)(__ballot(ib) >> gshift) & 0xFu;
+                float ta, tb, fa, fb;
+                box_interval_fast(rf, ea, ta, fa);
+                box_interval_fast(rf, eb, tb, fb);
+                // intersect_node (mesh.h:16-34) with prune_t = +inf until something is hit
+                const bool pa = (ea.w != WIDE_NONE) & !(ta > fa) & !(ta > prune_t);
+                const bool pb = (eb.w != WIDE_NONE) & !(tb > fb) & !(tb > prune_t);
+                const bool la = pa & ((int)ea.w < 0) & (ea.w != last_hit_w);
+                const bool lb = pb & ((int)eb.w < 0) & (eb.w != last_hit_w);
+                const bool ia = pa & ((int)ea.w >= 0), ib = pb & ((int)eb.w >= 0);
+                const uint32_t mla = QUAD_BITS(__ballot(la)), mlb = QUAD_BITS(__ballot(lb));
+                const uint32_t mia = QUAD_BITS(__ballot(ia)), mib = QUAD_BITS(__ballot(ib));
                 // postponed triangles: ring slots after the ones already there, lower lanes first
                 {
                     uint32_t off = phead + (uint32_t)npend + __popc(mla & below) + __popc(mlb & below);
@@ -1119,6 +1128,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     if (triangle_index == -1 || dm < min_distance || (dm == min_distance && rm < best_rank)) {
                         triangle_index = (int)wtri;
                         min_distance = dm;
+                        prune_t = dm;
                         best_rank = rm;
                     }
                 }
@@ -1138,6 +1148,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
         }
     }
 
+#undef QUAD_BITS
     if (COUNT) {
         unsigned long long nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
         if (lane == 0) {

@@ -264,6 +264,18 @@ __device__ inline float box_tmin_fast(const RayFast &r, uint4 nd)
     return (tmin > tmax) ? -1.0f : tmin;
 }
 
+// the same slab test returning the interval (the caller compares; no -1 encoding to undo)
+__device__ inline void box_interval_fast(const RayFast &r, uint4 nd, float &tmin, float &tmax)
+{
+    float t0x = cm_fmaf((float)(nd.x & 0xFFFFu), r.a.x, r.blo.x), t1x = cm_fmaf((float)(nd.x >> 16), r.a.x, r.bhi.x);
+    float t0y = cm_fmaf((float)(nd.y & 0xFFFFu), r.a.y, r.blo.y), t1y = cm_fmaf((float)(nd.y >> 16), r.a.y, r.bhi.y);
+    float t0z = cm_fmaf((float)(nd.z & 0xFFFFu), r.a.z, r.blo.z), t1z = cm_fmaf((float)(nd.z >> 16), r.a.z, r.bhi.z);
+    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                           __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+    tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                           __builtin_fmaxf(t0z, t1z));
+}
+
 // intersect_mesh (mesh.h:42-118), literally: the reference's order, its box arithmetic, every triangle
 // tested the moment its leaf box is entered.  Lanes are independent (no wave votes), so it is slow and
 // used where exactness matters more than speed: rays handed over by the fast walks, the fused
