@@ -481,3 +481,46 @@ def test_edge_inputs_in_a_large_batch(gpu, oracle_mod, tiny_geometry):
     assert got.flags[300] == (event.NO_HIT | event.NAN_ABORT) and got.flags[301] == (event.NO_HIT | event.NAN_ABORT)
     assert (got.flags[1000:1050] == event.NO_HIT).all()
     assert stats['launches'] == ostats['launches'] and stats['photon_steps'] == ostats['photon_steps']
+
+
+def test_large_batch_properties(gpu, oracle_mod, tiny_geometry):
+    """2e6 photons (too many for the oracle inside a test; tools/parity_sweep.py does that offline):
+    every ray cast -- 4, 8 or 1 lane per ray over the SAH tree, the reference tree in the reference's
+    order -- gives the same photons bit for bit, a repeated run is identical, and a 1e5 sample of the
+    batch, propagated alone by the ORACLE with the same per-photon streams, has the same ray-cast
+    answer for its first step."""
+    n = 2_000_000
+    ph = oracle_mod.generate_bomb(n, seed=77, wavelength_lo=400.0, wavelength_hi=650.0)
+    gg = gpu.GPUDetector(tiny_geometry)
+    results = {}
+    for mode in ('quad', 'quad', 'coop', 'wide', 'reference'):
+        gpu.get_context().set_walk(mode)
+        try:
+            gp = gpu.GPUPhotons(ph)
+            gp.propagate(gg, gpu.get_rng_states(64, seed=9), max_steps=100)
+            out = gp.get()
+        finally:
+            gpu.get_context().set_walk('quad')
+        if mode in results:
+            assert_bit_exact(out, results[mode], 'repeat of %s' % mode)
+        results[mode] = out
+    for mode in ('coop', 'wide', 'reference'):
+        assert_bit_exact(results[mode], results['quad'], '%s vs quad' % mode)
+    out = results['quad']
+    assert ((out.flags & event.TERMINAL_MASK) != 0).mean() > 0.999
+    # first step of a sample against the oracle: same triangle for the same ray
+    sample = ph[:100_000]
+    gp = gpu.GPUPhotons(sample)
+    gp.propagate(gg, gpu.get_rng_states(64, seed=9), max_steps=1)
+    want, _, _ = oracle_mod.propagate(pack_geometry_cached(tiny_geometry), sample, seed=9, max_steps=1)
+    assert_bit_exact(gp.get(), want, 'first step of the sample')
+
+
+_packed_cache = {}
+
+
+def pack_geometry_cached(geometry):
+    from chroma_amd.gpu.geometry import pack_geometry
+    if id(geometry) not in _packed_cache:
+        _packed_cache[id(geometry)] = pack_geometry(geometry)
+    return _packed_cache[id(geometry)]
