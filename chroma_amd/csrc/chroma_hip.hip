@@ -12,9 +12,12 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <chrono>
+#include <atomic>
 
 #include "propagate_device.h"
 #include "wide_build.h"
+#include "host_utils.h"
 
 // ---------------------------------------------------------------------------------------------------
 // error handling
@@ -2186,22 +2189,46 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
         return set_error(CHROMA_ERR_INVALID, "geometry: bad optics table sizes (8-bit signed material/surface indices)");
     if (!d->mat_refractive_index || !d->mat_absorption_length || !d->mat_scattering_length || !d->mat_num_comp || !d->mat_comp_offset)
         return set_error(CHROMA_ERR_INVALID, "geometry: missing material tables");
-    // host-side shape checks the kernels rely on
-    for (size_t i = 0; i < (size_t)d->ntriangles * 3; i++)
-        if (d->triangles[i] >= d->nvertices) return set_error(CHROMA_ERR_INVALID, "triangle %zu references vertex %u >= %u", i / 3, d->triangles[i], d->nvertices);
-    for (size_t i = 0; i < d->nnodes; i++) {
-        uint32_t w = d->nodes[4 * i + 3];
-        uint32_t nchild = w >> CHROMA_CHILD_BITS, child = w & ~CHROMA_NCHILD_MASK;
-        if (nchild == 0) { if (child >= d->ntriangles) return set_error(CHROMA_ERR_INVALID, "leaf node %zu references triangle %u >= %u", i, child, d->ntriangles); }
-        else if ((size_t)child + nchild > d->nnodes || child <= i) return set_error(CHROMA_ERR_INVALID, "node %zu has a bad child range [%u, %u)", i, child, child + nchild);
-    }
-    for (size_t i = 0; i < d->ntriangles; i++) {
-        uint32_t code = d->material_codes[i];
-        int inner = (int8_t)(code >> 24), outer = (int8_t)(code >> 16), surf = (int8_t)(code >> 8);
-        if (inner < 0 || outer < 0 || inner >= (int)d->nmaterials || outer >= (int)d->nmaterials || surf < -1 || surf >= (int)d->nsurfaces)
-            return set_error(CHROMA_ERR_INVALID, "triangle %zu has material code 0x%08x outside the tables", i, code);
-        if (d->nsolids && d->solid_id_map && d->solid_id_map[i] >= d->nsolids)
+    // host-side shape checks the kernels rely on (all cores; the first offender in index order is reported)
+    {
+        using chroma_host::parallel_for;
+        std::atomic<size_t> bad_tri(SIZE_MAX), bad_node(SIZE_MAX), bad_code(SIZE_MAX);
+        auto note = [](std::atomic<size_t> &slot, size_t i) { size_t cur = slot.load(); while (i < cur && !slot.compare_exchange_weak(cur, i)) {} };
+        parallel_for((size_t)d->ntriangles * 3, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) if (d->triangles[i] >= d->nvertices) { note(bad_tri, i); break; }
+        });
+        if (bad_tri != SIZE_MAX) { size_t i = bad_tri; return set_error(CHROMA_ERR_INVALID, "triangle %zu references vertex %u >= %u", i / 3, d->triangles[i], d->nvertices); }
+        parallel_for((size_t)d->nnodes, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                uint32_t w = d->nodes[4 * i + 3];
+                uint32_t nchild = w >> CHROMA_CHILD_BITS, child = w & ~CHROMA_NCHILD_MASK;
+                bool bad = nchild == 0 ? child >= d->ntriangles : ((size_t)child + nchild > d->nnodes || child <= i);
+                if (bad) { note(bad_node, i); break; }
+            }
+        });
+        if (bad_node != SIZE_MAX) {
+            size_t i = bad_node;
+            uint32_t w = d->nodes[4 * i + 3], nchild = w >> CHROMA_CHILD_BITS, child = w & ~CHROMA_NCHILD_MASK;
+            if (nchild == 0) return set_error(CHROMA_ERR_INVALID, "leaf node %zu references triangle %u >= %u", i, child, d->ntriangles);
+            return set_error(CHROMA_ERR_INVALID, "node %zu has a bad child range [%u, %u)", i, child, child + nchild);
+        }
+        parallel_for((size_t)d->ntriangles, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                uint32_t code = d->material_codes[i];
+                int inner = (int8_t)(code >> 24), outer = (int8_t)(code >> 16), surf = (int8_t)(code >> 8);
+                bool bad = inner < 0 || outer < 0 || inner >= (int)d->nmaterials || outer >= (int)d->nmaterials || surf < -1 || surf >= (int)d->nsurfaces;
+                if (!bad && d->nsolids && d->solid_id_map && d->solid_id_map[i] >= d->nsolids) bad = true;
+                if (bad) { note(bad_code, i); break; }
+            }
+        });
+        if (bad_code != SIZE_MAX) {
+            size_t i = bad_code;
+            uint32_t code = d->material_codes[i];
+            int inner = (int8_t)(code >> 24), outer = (int8_t)(code >> 16), surf = (int8_t)(code >> 8);
+            if (inner < 0 || outer < 0 || inner >= (int)d->nmaterials || outer >= (int)d->nmaterials || surf < -1 || surf >= (int)d->nsurfaces)
+                return set_error(CHROMA_ERR_INVALID, "triangle %zu has material code 0x%08x outside the tables", i, code);
             return set_error(CHROMA_ERR_INVALID, "triangle %zu has solid id %u >= %u", i, d->solid_id_map[i], d->nsolids);
+        }
     }
     for (uint32_t m = 0; m < d->nmaterials; m++)
         if (d->mat_num_comp[m] && d->mat_comp_offset[m] + d->mat_num_comp[m] > d->ncomp_total)
@@ -2215,6 +2242,15 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
         }
     }
 
+    const bool timing = getenv("CHROMA_TIMING") != nullptr;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char *what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[chroma_geometry_create] %-28s %.2f s\n", what, std::chrono::duration<double>(now - t_phase).count());
+        t_phase = now;
+    };
+    phase("validation");
     HIP_TRY(hipSetDevice(ctx->device));
     chroma_geometry *g = new chroma_geometry;
     g->ctx = ctx;
@@ -2234,6 +2270,7 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
             return set_error(CHROMA_ERR_INVALID, "%s", werr.c_str());
         }
     }
+    phase("nodes upload + wide tree");
     const std::vector<uint32_t> &tri_to_dev = wt.tri_to_dev, &dev_to_tri = wt.dev_to_tri;
     const size_t nrecords = dev_to_tri.size();
     { const uint4 *p; if ((rc = upload(g, (const uint4 *)wt.wnodes.data(), wt.nwide * 8, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } v.wnodes = p; }
@@ -2255,15 +2292,18 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
         for (size_t n0 = 0; n0 < d->nnodes; n0 += CH) {
             size_t n1 = std::min((size_t)d->nnodes, n0 + CH);
             memcpy(stage.data(), d->nodes + 4 * n0, (n1 - n0) * 16);
-            for (size_t i = 0; i < n1 - n0; i++) {
-                uint32_t w = stage[4 * i + 3];
-                if ((w >> CHROMA_CHILD_BITS) == 0) stage[4 * i + 3] = tri_to_dev[w & ~CHROMA_NCHILD_MASK];
-            }
+            chroma_host::parallel_for(n1 - n0, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; i++) {
+                    uint32_t w = stage[4 * i + 3];
+                    if ((w >> CHROMA_CHILD_BITS) == 0) stage[4 * i + 3] = tri_to_dev[w & ~CHROMA_NCHILD_MASK];
+                }
+            });
             e = hipMemcpy((char *)dn + n0 * 16, stage.data(), (n1 - n0) * 16, hipMemcpyHostToDevice);
             if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "node upload: %s", hipGetErrorString(e)); }
         }
         v.nodes = (const uint4 *)dn;
     }
+    phase("wide nodes + traversal copy");
     // 48-byte triangle records in device order, staged in chunks
     {
         void *dtri = nullptr;
@@ -2276,21 +2316,24 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
         std::vector<float> stage(std::min(nrecords, CH) * 12);
         for (size_t t0 = 0; t0 < nrecords; t0 += CH) {
             size_t t1 = std::min(nrecords, t0 + CH);
-            for (size_t k = t0; k < t1; k++) {
-                size_t t = dev_to_tri[k];
-                float *r = stage.data() + (k - t0) * 12;
-                for (int c = 0; c < 3; c++) {
-                    const float *vv = d->vertices + 3 * (size_t)d->triangles[3 * t + c];
-                    r[4 * c] = vv[0]; r[4 * c + 1] = vv[1]; r[4 * c + 2] = vv[2];
+            chroma_host::parallel_for(t1 - t0, [&](size_t lo, size_t hi) {
+                for (size_t k = t0 + lo; k < t0 + hi; k++) {
+                    size_t t = dev_to_tri[k];
+                    float *r = stage.data() + (k - t0) * 12;
+                    for (int c = 0; c < 3; c++) {
+                        const float *vv = d->vertices + 3 * (size_t)d->triangles[3 * t + c];
+                        r[4 * c] = vv[0]; r[4 * c + 1] = vv[1]; r[4 * c + 2] = vv[2];
+                    }
+                    uint32_t code = d->material_codes[t], tid = (uint32_t)t, rank = wt.rank[t];
+                    memcpy(&r[3], &code, 4); memcpy(&r[7], &tid, 4); memcpy(&r[11], &rank, 4);
                 }
-                uint32_t code = d->material_codes[t], tid = (uint32_t)t, rank = wt.rank[t];
-                memcpy(&r[3], &code, 4); memcpy(&r[7], &tid, 4); memcpy(&r[11], &rank, 4);
-            }
+            });
             e = hipMemcpy((char *)dtri + t0 * 48, stage.data(), (t1 - t0) * 48, hipMemcpyHostToDevice);
             if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "triangle upload: %s", hipGetErrorString(e)); }
         }
         v.tri = (const float4 *)dtri;
     }
+    phase("triangle records");
     // API-visible copies of the mesh arrays (GPUGeometry.vertices/.triangles/.material_codes/.colors)
     { const float *p; if ((rc = upload(g, d->vertices, (size_t)d->nvertices * 3, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_vertices = (void *)p; }
     { const uint32_t *p; if ((rc = upload(g, d->triangles, (size_t)d->ntriangles * 3, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_triangles = (void *)p; }
@@ -2341,7 +2384,9 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     v.time_n = d->time_n; v.time_start = d->time_start; v.time_step = d->time_step;
     v.nnodes = d->nnodes; v.ntriangles = d->ntriangles; v.nsolids = d->nsolids; v.nchannels = d->nchannels;
 
+    phase("mesh arrays + tables");
     g->stack_need = compute_stack_need(d->nodes, d->nnodes);
+    phase("stack need");
     if (g->stack_need > STACK_LDS + STACK_SCRATCH) {
         uint32_t need = g->stack_need;
         chroma_geometry_destroy(g);

@@ -22,6 +22,8 @@
 #include <string.h>
 #include <stdlib.h>
 #include <atomic>
+#include <chrono>
+#include <stdio.h>
 #include <thread>
 
 namespace chroma_host {
@@ -277,15 +279,34 @@ static uint32_t build_subtree(Prim *prims, size_t first, size_t count, std::vect
 
 static int sah_topology(const uint32_t *ref, uint32_t ntriangles, const std::vector<uint32_t> &leaf_node, WideTree &out, std::string &err)
 {
+    // one primitive per triangle that hangs under a reachable leaf, in triangle order (threaded: count, place)
     std::vector<Prim> prims;
-    prims.reserve(ntriangles);
-    for (uint32_t t = 0; t < ntriangles; t++) {
-        if (leaf_node[t] == 0xFFFFFFFFu) continue;
-        const uint32_t *nd = ref + 4 * (size_t)leaf_node[t];
-        Prim p;
-        for (int a = 0; a < 3; a++) { p.lo[a] = (uint16_t)(nd[a] & 0xFFFFu); p.hi[a] = (uint16_t)(nd[a] >> 16); }
-        p.tri = t;
-        prims.push_back(p);
+    {
+        const unsigned nt = hw_threads();
+        const size_t chunk = ((size_t)ntriangles + nt - 1) / nt;
+        std::vector<size_t> start(nt + 1, 0);
+        parallel_for(nt, [&](size_t a, size_t b) {
+            for (size_t k = a; k < b; k++) {
+                size_t lo = std::min<size_t>(ntriangles, k * chunk), hi = std::min<size_t>(ntriangles, lo + chunk), c = 0;
+                for (size_t t = lo; t < hi; t++) c += leaf_node[t] != 0xFFFFFFFFu;
+                start[k + 1] = c;
+            }
+        }, 1);
+        for (unsigned k = 0; k < nt; k++) start[k + 1] += start[k];
+        prims.resize(start[nt]);
+        parallel_for(nt, [&](size_t a, size_t b) {
+            for (size_t k = a; k < b; k++) {
+                size_t lo = std::min<size_t>(ntriangles, k * chunk), hi = std::min<size_t>(ntriangles, lo + chunk), o = start[k];
+                for (size_t t = lo; t < hi; t++) {
+                    if (leaf_node[t] == 0xFFFFFFFFu) continue;
+                    const uint32_t *nd = ref + 4 * (size_t)leaf_node[t];
+                    Prim p;
+                    for (int ax = 0; ax < 3; ax++) { p.lo[ax] = (uint16_t)(nd[ax] & 0xFFFFu); p.hi[ax] = (uint16_t)(nd[ax] >> 16); }
+                    p.tri = (uint32_t)t;
+                    prims[o++] = p;
+                }
+            }
+        }, 1);
     }
     const size_t np = prims.size();
     if (np > 0x7FFFFFFFull) { err = "wide tree: too many triangles"; return -1; }
@@ -394,6 +415,14 @@ static int sah_topology(const uint32_t *ref, uint32_t ntriangles, const std::vec
 
 int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, WideTree &out, std::string &err, int topology)
 {
+    const bool timing = getenv("CHROMA_TIMING") != nullptr;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char *what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[build_wide_tree] %-28s %.2f s\n", what, std::chrono::duration<double>(now - t_phase).count());
+        t_phase = now;
+    };
     out = WideTree();
     if (!nodes || nnodes == 0) { err = "wide tree: no nodes"; return -1; }
 
@@ -477,6 +506,7 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
     if (bad) { err = "wide tree: leaf references a triangle outside the mesh"; return -1; }
     { std::vector<uint32_t>().swap(base); std::vector<uint32_t>().swap(leaves); }
 
+    phase("reference test order");
     out.tri_to_dev.assign(ntriangles, 0xFFFFFFFFu);
     out.dev_to_tri.clear();
     if (topology == WIDE_TOPOLOGY_SAH) {
@@ -560,6 +590,7 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
     out.depth = depth;
     }
 
+    phase("topology");
     // worst case of the walk's stack: at a node, every inner child but the one walked next is
     // pushed, then the same below -- whichever child is walked, so the maximum over children
     {
@@ -585,6 +616,7 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
     }
     for (uint32_t t = 0; t < ntriangles; t++)
         if (out.tri_to_dev[t] == 0xFFFFFFFFu) { out.tri_to_dev[t] = (uint32_t)out.dev_to_tri.size(); out.dev_to_tri.push_back(t); }
+    phase("stack need + record map");
     return 0;
 }
 
