@@ -234,7 +234,20 @@ struct Segment { size_t first, count; IBox box; };
 static IBox segment_box(const Prim *prims, size_t first, size_t count)
 {
     IBox b; b.clear();
-    for (size_t i = first; i < first + count; i++) b.add(prims[i]);
+    if (count < (1u << 20)) {
+        for (size_t i = first; i < first + count; i++) b.add(prims[i]);
+        return b;
+    }
+    const unsigned nt = hw_threads();
+    const size_t chunk = (count + nt - 1) / nt;
+    std::vector<IBox> part(nt);
+    parallel_for(nt, [&](size_t a, size_t e) {
+        for (size_t t = a; t < e; t++) {
+            size_t lo = std::min(count, t * chunk), hi = std::min(count, lo + chunk);
+            for (size_t i = first + lo; i < first + hi; i++) part[t].add(prims[i]);
+        }
+    }, 1);
+    for (auto &p : part) if (!p.empty()) b.add(p);
     return b;
 }
 
