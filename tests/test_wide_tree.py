@@ -154,3 +154,17 @@ def test_malformed_tree_is_rejected():
     bad = np.array([[0, 0, 0, 2 << 28 | 5]], dtype=np.uint32)          # children outside the array
     with pytest.raises(_lib.ChromaError):
         _lib.wide_build(bad, 1)
+
+
+def test_build_is_repeatable():
+    """Node order and record order do not depend on thread timing: two builds are identical."""
+    for name, g in _geometries():
+        if name != 'tiny':
+            continue
+        nodes = np.ascontiguousarray(g.bvh.nodes)
+        for topology in ('sah', 'collapse'):
+            a = _wide(nodes, len(g.mesh.triangles), topology)
+            b = _wide(nodes, len(g.mesh.triangles), topology)
+            for key in ('wnodes', 'tri_to_record', 'record_to_tri', 'rank'):
+                assert np.array_equal(a[key], b[key]), (topology, key)
+            assert a['depth'] == b['depth']
