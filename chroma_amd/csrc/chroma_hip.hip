@@ -2004,6 +2004,91 @@ static uint32_t compute_stack_need(const uint32_t *nodes, size_t nnodes)
     return std::max<uint32_t>(1, need[0]);
 }
 
+// ---- distance_to_mesh through the fast ray cast --------------------------------------------------------
+// mesh.h:124-151 asks for the nearest triangle along free rays.  Same pipeline as a propagation step:
+// ray records, k_raycast_quad, the check that the reference tests the winner (record_hit_is_regular),
+// the literal reference walk for the rays that fail it or that the fast walk cannot take.
+__global__ void k_rays_from_arrays(GeoView g, int n, const float *origin_in, const float *direction_in, float4 *rays,
+                                   int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, StepState *st)
+{
+    int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    v3 origin = load3(origin_in, slot), direction = load3(direction_in, slot);
+    direction = direction / norm(direction);
+    v3 noid = (-origin) / direction;
+    v3 inv_dir = 1.0f / direction;
+    bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                    cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+    int status = moderate ? 0 : HIT_RETRY;                 // (a NaN ray is not moderate: the literal walk answers)
+    v3 a = mk3(0.f, 0.f, 0.f), b = mk3(0.f, 0.f, 0.f);
+    if (moderate) {
+        a = ray_fast(g, noid, inv_dir).a;
+        b = mk3(cm_fmaf(g.world_origin[0], inv_dir.x, noid.x), cm_fmaf(g.world_origin[1], inv_dir.y, noid.y),
+                cm_fmaf(g.world_origin[2], inv_dir.z, noid.z));
+    }
+    float4 *r = rays + 4 * (size_t)slot;
+    r[0] = make_float4(origin.x, origin.y, origin.z, __int_as_float(-1));
+    r[1] = make_float4(direction.x, direction.y, direction.z, __int_as_float(status));
+    r[2] = make_float4(a.x, a.y, a.z, 0.0f);
+    r[3] = make_float4(b.x, b.y, b.z, 0.0f);
+    if (status != 0) {
+        hit_triangle[slot] = status;
+        hit_distance[slot] = 0.0f;
+        retry_list[atomicAdd(&st->retry, 1u)] = (uint32_t)slot;
+    }
+}
+__global__ void k_step_set(StepState *st, uint32_t n) { st->n = n; st->renorm = 0u; st->in_tail = 0u; st->launches = 0u; st->work = 0u; st->retry = 0u; }
+
+// results of the fast cast: checked, translated to triangle ids, or handed to the literal walk
+__global__ void k_distance_finish(GeoView g, int n, const float4 *rays, const int32_t *hit_triangle, const float *hit_distance,
+                                  float *distance_out, int32_t *triangle_out, uint32_t *retry_list, StepState *st)
+{
+    int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    int rec = hit_triangle[slot];
+    if (rec == HIT_RETRY) return;                          // already listed
+    if (rec >= 0) {
+        const float4 *r = rays + 4 * (size_t)slot;
+        const float4 r0 = r[0], r1 = r[1];
+        const float4 *t = g.tri + 3 * (size_t)rec;
+        const float4 a = t[0], b = t[1], c = t[2];
+        const float dist = hit_distance[slot];
+        if (!record_hit_is_regular(g, a, b, c, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), dist)) {
+            retry_list[atomicAdd(&st->retry, 1u)] = (uint32_t)slot;
+            return;
+        }
+        distance_out[slot] = dist;
+        if (triangle_out) triangle_out[slot] = (int32_t)__float_as_uint(b.w);
+    } else if (triangle_out) {
+        triangle_out[slot] = -1;                           // a miss leaves the distance untouched (mesh.h:145-148)
+    }
+}
+template <bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK) void
+k_distance_retry(GeoView g, const float4 *rays, const StepState *st, const uint32_t *retry_list, float *distance_out,
+                 int32_t *triangle_out, DeviceCounters *counters)
+{
+    __shared__ uint32_t s_lds[TRAV_LDS_WORDS(STACK_LDS, PROP_BLOCK)];
+    const int nretry = (int)st->retry;
+    LaneCounters cnt = {0, 0, 0, 0};
+    for (int k = blockIdx.x * PROP_BLOCK + threadIdx.x; k < nretry; k += gridDim.x * PROP_BLOCK) {
+        const int slot = (int)retry_list[k];
+        const float4 *r = rays + 4 * (size_t)slot;
+        const float4 r0 = r[0], r1 = r[1];
+        float dist;
+        int rec = intersect_mesh_dev<STACK_LDS, PROP_BLOCK, COUNT>(g, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), dist, -1,
+                                                                   s_lds + threadIdx.x, cnt, true);
+        if (rec >= 0) distance_out[slot] = dist;
+        if (triangle_out) triangle_out[slot] = rec >= 0 ? (int32_t)g.dev_to_tri[rec] : -1;
+    }
+    unsigned long long ov = wave_sum_u64(cnt.overflows);
+    if (COUNT) {
+        unsigned long long nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        if (lane_id() == 0) { atomicAdd(&counters->nodes_visited, nd); atomicAdd(&counters->triangles_tested, tr); }
+    }
+    if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------
@@ -2549,19 +2634,56 @@ int chroma_copy_photon_hits(chroma_ctx *ctx, chroma_geometry *geom, int32_t firs
     return rc;
 }
 
+static int ensure_queues(chroma_ctx *ctx, size_t n);
+static int distance_to_mesh_fast(chroma_ctx *ctx, chroma_geometry *geom, int32_t n, const float *d_origin,
+                                 const float *d_direction, float *d_distance, int32_t *d_triangle);
+
 int chroma_distance_to_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthreads, const float *d_origin,
                             const float *d_direction, float *d_distance, int32_t *d_triangle)
 {
     if (!ctx || !geom || !d_origin || !d_direction || !d_distance) return set_error(CHROMA_ERR_INVALID, "bad argument");
     if (nthreads <= 0) return CHROMA_OK;
-    dim3 grid((unsigned)((nthreads + PROP_BLOCK - 1) / PROP_BLOCK)), block(PROP_BLOCK);
     uint32_t need = geom->stack_need;
-#define LAUNCH(N, C) hipLaunchKernelGGL((k_distance_to_mesh<N, C>), grid, block, 0, ctx->stream, geom->view, nthreads, \
-                                        d_origin, d_direction, d_distance, d_triangle, ctx->d_counters)
     if (need > STACK_LDS + STACK_SCRATCH)
         return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
+    if (geom->view.wnodes && geom->wide_stack_need <= COOP_STACK + COOP_SPILL && ctx->wide_walk != CHROMA_WALK_REFERENCE)
+        return distance_to_mesh_fast(ctx, geom, nthreads, d_origin, d_direction, d_distance, d_triangle);
+    dim3 grid((unsigned)((nthreads + PROP_BLOCK - 1) / PROP_BLOCK)), block(PROP_BLOCK);
+#define LAUNCH(N, C) hipLaunchKernelGGL((k_distance_to_mesh<N, C>), grid, block, 0, ctx->stream, geom->view, nthreads, \
+                                        d_origin, d_direction, d_distance, d_triangle, ctx->d_counters)
     if (ctx->counting) LAUNCH(STACK_LDS, true); else LAUNCH(STACK_LDS, false);
 #undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+static int distance_to_mesh_fast(chroma_ctx *ctx, chroma_geometry *geom, int32_t n, const float *d_origin,
+                                 const float *d_direction, float *d_distance, int32_t *d_triangle)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_queues(ctx, (size_t)n); if (rc) return rc;
+    if (!ctx->coop_spill)
+        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, (size_t)ctx->coop_waves * 16 * COOP_SPILL * sizeof(uint2)));
+    StepState *st = ctx->d_step;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_step_set, dim3(1), dim3(1), 0, ctx->stream, st, (uint32_t)n);
+    hipLaunchKernelGGL(k_rays_from_arrays, dim3(blocks), dim3(256), 0, ctx->stream, geom->view, (int)n, d_origin, d_direction,
+                       ctx->rays, ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, st);
+    const unsigned waves = (unsigned)std::min<long long>(((long long)n + 15) / 16, (long long)ctx->quad_waves);
+    if (ctx->counting)
+        hipLaunchKernelGGL((k_raycast_quad<true>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, 0, st,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk);
+    else
+        hipLaunchKernelGGL((k_raycast_quad<false>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, 0, st,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk);
+    hipLaunchKernelGGL(k_distance_finish, dim3(blocks), dim3(256), 0, ctx->stream, geom->view, (int)n, ctx->rays, ctx->hit_triangle,
+                       ctx->hit_distance, d_distance, d_triangle, ctx->retry_list, st);
+    if (ctx->counting)
+        hipLaunchKernelGGL((k_distance_retry<true>), dim3(256), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
+                           ctx->retry_list, d_distance, d_triangle, ctx->d_counters);
+    else
+        hipLaunchKernelGGL((k_distance_retry<false>), dim3(256), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
+                           ctx->retry_list, d_distance, d_triangle, ctx->d_counters);
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
 }
