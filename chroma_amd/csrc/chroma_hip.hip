@@ -1287,7 +1287,8 @@ __device__ inline int coop_cast(const GeoView &g, v3 origin, v3 direction, int l
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
 k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input_queue, uint32_t *output_queue,
-            uint64_t seed, uint64_t id_base, int max_steps, int scatter_first, uint2 *spill_base, DeviceCounters *counters)
+            uint64_t seed, uint64_t id_base, int max_steps, int use_weights, int scatter_first, uint2 *spill_base,
+            DeviceCounters *counters)
 {
     __shared__ uint32_t s_coop[8 * COOP_STRIDE];
     __shared__ uint32_t s_walk[TRAV_LDS_WORDS(STACK_LDS, PROP_BLOCK)];
@@ -1367,7 +1368,7 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input
                 live = false;
                 last_hit_dev = -1;
             } else {
-                live = step_after_hit(p, s, rng, g, false, scatter_first);
+                live = step_after_hit(p, s, rng, g, use_weights != 0, scatter_first);
                 scatter_first = 0;
                 last_hit_dev = (p.last_hit_triangle < 0) ? -1 : record;
             }
@@ -1888,7 +1889,9 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     dim3 grid(waves), block(PROP_BLOCK);
     StepState *st = ctx->d_step;
     const uint32_t *q = in_q + 1;
-    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st, (uint32_t)(PROP_BLOCK * 16 * 8));
+    // (with weights the reference runs ALL steps in one launch: every count is "few")
+    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st,
+                       use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8));
     if (ev) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
     if (quad || coop) {
         unsigned sblocks = (unsigned)std::min<long long>((n_upper + 255) / 256, (long long)ctx->physics_blocks * 4);
@@ -1937,7 +1940,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
 // All remaining steps of the last photons in one launch (k_tail_coop).  Returns CHROMA_OK and sets
 // *done when the geometry has a wide tree the kernel can walk; otherwise leaves *done false.
 static int launch_tail(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, long long n_upper, const uint32_t *in_q,
-                       uint32_t *out_q, chroma_rng rng, int nsteps, int scatter_first, hipEvent_t *ev, bool *done)
+                       uint32_t *out_q, chroma_rng rng, int nsteps, int use_weights, int scatter_first, hipEvent_t *ev, bool *done)
 {
     *done = false;
     if (!geom->view.wnodes || geom->wide_stack_need > COOP_STACK + COOP_SPILL || geom->stack_need > STACK_LDS + STACK_SCRATCH)
@@ -1949,14 +1952,15 @@ static int launch_tail(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, lo
     unsigned waves = (unsigned)std::min<long long>((n_upper + 7) / 8, (long long)ctx->coop_waves);
     if ((long long)waves * 8 < n_upper) return CHROMA_OK;          // (cannot happen below 8192 photons)
     StepState *st = ctx->d_step;
-    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st, (uint32_t)(PROP_BLOCK * 16 * 8));
+    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st,
+                       use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8));
     if (ev) { HIP_TRY(hipEventRecord(ev[0], ctx->stream)); HIP_TRY(hipEventRecord(ev[1], ctx->stream)); }
     if (ctx->counting)
         hipLaunchKernelGGL((k_tail_coop<true>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, in_q + 1, out_q,
-                           rng.seed, rng.photon_id_base, nsteps, scatter_first, ctx->coop_spill, ctx->d_counters);
+                           rng.seed, rng.photon_id_base, nsteps, use_weights, scatter_first, ctx->coop_spill, ctx->d_counters);
     else
         hipLaunchKernelGGL((k_tail_coop<false>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, in_q + 1, out_q,
-                           rng.seed, rng.photon_id_base, nsteps, scatter_first, ctx->coop_spill, ctx->d_counters);
+                           rng.seed, rng.photon_id_base, nsteps, use_weights, scatter_first, ctx->coop_spill, ctx->d_counters);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(hipGetLastError());
     *done = true;
@@ -2776,10 +2780,11 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     // with weights).  A launch re-normalises dir/pol when it loads a photon (propagate.cu:248,250), so
     // the policy is part of the arithmetic.  Without weights every step here is a ray cast + physics
     // pair that gets the whole chip; a step that the reference would run inside its last launch skips
-    // the re-normalisation instead (same numbers).  The policy is evaluated ON THE DEVICE
+    // the re-normalisation instead (same numbers; with weights that is every step but the first).  The
+    // policy is evaluated ON THE DEVICE
     // (k_step_begin), so the steps are enqueued back to back; the host looks at the survivor count
     // only now and then, to stop early and to shrink the grids.
-    const bool device_steps = !use_weights && ctx->split_tail;
+    const bool device_steps = ctx->split_tail != 0;
     if (device_steps) {
         HIP_TRY(hipMemsetAsync(ctx->d_step, 0, sizeof(StepState), ctx->stream));
         const int nev = time_kernels ? 4 * max_steps : 0;
@@ -2794,7 +2799,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
             if (fused_tail && n_upper < few) {
                 // the reference's last launch: all remaining steps at once, 8 lanes per photon
                 bool launched = false;
-                rc = launch_tail(ctx, geom, pv, n_upper, in_q, out_q, rng, max_steps - step, step == 0 ? scatter_first : 0,
+                rc = launch_tail(ctx, geom, pv, n_upper, in_q, out_q, rng, max_steps - step, use_weights, step == 0 ? scatter_first : 0,
                                  time_kernels ? ctx->step_events.data() + 4 * step : nullptr, &launched);
                 if (rc) return rc;
                 if (launched) {
@@ -2803,7 +2808,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                     break;
                 }
             }
-            rc = launch_split_step(ctx, geom, pv, n_upper, in_q, out_q, rng, 0, step == 0 ? scatter_first : 0,
+            rc = launch_split_step(ctx, geom, pv, n_upper, in_q, out_q, rng, use_weights, step == 0 ? scatter_first : 0,
                                    time_kernels ? ctx->step_events.data() + 4 * step : nullptr);
             if (rc) return rc;
             if (time_kernels) steps_timed = step + 1;
