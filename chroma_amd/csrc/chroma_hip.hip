@@ -61,9 +61,9 @@ struct chroma_ctx {
     // (triangle, distance) per queue slot handed from k_raycast to k_physics
     int32_t *hit_triangle = nullptr;
     float *hit_distance = nullptr;
-    int32_t *last_hit_dev = nullptr;       // [capacity] last_hit_triangles as record indices (PhotonView::last_hit_dev)
     uint32_t *retry_list = nullptr;        // [capacity] queue slots handed to k_raycast_retry
     float4 *rays = nullptr;                // [capacity][4] ray records (k_ray_setup)
+    float4 *work_a = nullptr, *work_b = nullptr;    // [capacity][4] the dense working sets that go with queue_a / queue_b
     // small device scratch: [0..3] DeviceCounters, then misc words
     DeviceCounters *d_counters = nullptr;
     uint32_t *d_words = nullptr;        // 16 words
@@ -236,39 +236,35 @@ __global__ void k_step_begin(const uint32_t *in_queue, uint32_t *out_queue, Step
 // executed by the whole wave for the few rays being refilled -- a quarter of the kernel's VALU work.
 // A record is 64 bytes at the queue slot: {origin, last hit record}, {direction, status},
 // {a = scale/d}, {b = (world_origin - o)/d} (RayFast: blo = b - a, bhi = b + a).  Status 0 = cast; the
-// other slots (terminal photon, NaN, 1/d not moderate) get their hit entry -- and their place in the
-// retry list -- right here.
+// other slots (NaN, 1/d not moderate) get their hit entry -- and their place in the retry list -- right
+// here.  The photon comes from the dense working set (see k_load_working).
 __global__ __launch_bounds__(256) void
-k_ray_setup(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input_queue, float4 *rays,
+k_ray_setup(GeoView g, const float4 *work, const StepState *st, float4 *rays,
             int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint32_t *retry_counter)
 {
     const int nthreads = (int)st->n, renorm = (int)st->renorm;
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < nthreads; slot += gridDim.x * blockDim.x) {
-        uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
-        int status = HIT_SKIP;
-        v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f), a = mk3(0.f, 0.f, 0.f), b = mk3(0.f, 0.f, 0.f);
-        int last_hit = -1;
-        if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
-            origin = load3(pv.pos, photon_id);
-            direction = load3(pv.dir, photon_id);
-            if (renorm) direction = direction / norm(direction);
-            if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
-                status = HIT_NAN;
+        const float4 *w = work + 4 * (size_t)slot;
+        const float4 w0 = w[0], w1 = w[1], w3 = w[3];
+        int status;
+        v3 origin = mk3(w0.x, w0.y, w0.z), direction = mk3(w1.x, w1.y, w1.z), a = mk3(0.f, 0.f, 0.f), b = mk3(0.f, 0.f, 0.f);
+        const int last_hit = __float_as_int(w3.z);
+        if (renorm) direction = direction / norm(direction);
+        if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
+            status = HIT_NAN;
+        } else {
+            v3 noid = (-origin) / direction;
+            v3 inv_dir = 1.0f / direction;
+            bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                            cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+            if (!moderate) {
+                status = HIT_RETRY;
             } else {
-                v3 noid = (-origin) / direction;
-                v3 inv_dir = 1.0f / direction;
-                bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
-                                cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
-                if (!moderate) {
-                    status = HIT_RETRY;
-                } else {
-                    a = ray_fast(g, noid, inv_dir).a;
-                    // b exactly as ray_fast forms it (blo = b - a, bhi = b + a are rebuilt by the kernels)
-                    b = mk3(cm_fmaf(g.world_origin[0], inv_dir.x, noid.x), cm_fmaf(g.world_origin[1], inv_dir.y, noid.y),
-                            cm_fmaf(g.world_origin[2], inv_dir.z, noid.z));
-                    last_hit = pv.last_hit_dev[photon_id];
-                    status = 0;
-                }
+                a = ray_fast(g, noid, inv_dir).a;
+                // b exactly as ray_fast forms it (blo = b - a, bhi = b + a are rebuilt by the kernels)
+                b = mk3(cm_fmaf(g.world_origin[0], inv_dir.x, noid.x), cm_fmaf(g.world_origin[1], inv_dir.y, noid.y),
+                        cm_fmaf(g.world_origin[2], inv_dir.z, noid.z));
+                status = 0;
             }
         }
         float4 *r = rays + 4 * (size_t)slot;
@@ -301,10 +297,10 @@ k_ray_setup(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input
 
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
-k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
+k_raycast_persistent(GeoView g, const float4 *rays, int first_photon, StepState *st,
                      int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, DeviceCounters *counters)
 {
-    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    const int nthreads = (int)st->n;
     if ((long long)blockIdx.x * PROP_BLOCK >= nthreads) return;
     uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
     __shared__ uint32_t s_lds[(RAY_LDS_STACK + TRAV_PENDING) * PROP_BLOCK];
@@ -338,45 +334,30 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, StepState *st, 
                 uint32_t idx = base + (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
                 if (idx < (uint32_t)nthreads) {
                     slot = first_photon + (int)idx;
-                    uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
-                    int result = HIT_SKIP;
-                    if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
-                        origin = load3(pv.pos, photon_id);
-                        direction = load3(pv.dir, photon_id);
-                        if (renorm) direction = direction / norm(direction);
-                        if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
-                            result = HIT_NAN;
+                    const float4 *r = rays + 4 * (size_t)slot;
+                    const float4 r0 = r[0], r1 = r[1];
+                    if (__float_as_int(r1.w) == 0) {             // (other slots were settled by k_ray_setup)
+                        const float4 r2 = r[2], r3 = r[3];
+                        origin = mk3(r0.x, r0.y, r0.z);
+                        direction = mk3(r1.x, r1.y, r1.z);
+                        last_hit = __float_as_int(r0.w);
+                        rf.a = mk3(r2.x, r2.y, r2.z);
+                        const v3 bb = mk3(r3.x, r3.y, r3.z);
+                        rf.blo = bb - rf.a;
+                        rf.bhi = bb + rf.a;
+                        triangle_index = -1;
+                        min_distance = -1.0f;
+                        sp = 0;
+                        npend = 0;
+                        uint4 root = g.nodes[0];
+                        has_ray = true;
+                        if (node_passes(box_tmin_fast(rf, root), min_distance)) {
+                            active = true;
+                            cur = root.w & ~CHROMA_NCHILD_MASK;
+                            end = cur + (root.w >> CHROMA_CHILD_BITS) - 1;
                         } else {
-                            v3 noid = (-origin) / direction;
-                            v3 inv_dir = 1.0f / direction;
-                            bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
-                                            cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
-                            if (!moderate) {
-                                result = HIT_RETRY;
-                            } else {
-                                rf = ray_fast(g, noid, inv_dir);
-                                last_hit = pv.last_hit_dev[photon_id];
-                                triangle_index = -1;
-                                min_distance = -1.0f;
-                                sp = 0;
-                                npend = 0;
-                                uint4 root = g.nodes[0];
-                                has_ray = true;
-                                if (node_passes(box_tmin_fast(rf, root), min_distance)) {
-                                    active = true;
-                                    cur = root.w & ~CHROMA_NCHILD_MASK;
-                                    end = cur + (root.w >> CHROMA_CHILD_BITS) - 1;
-                                } else {
-                                    active = false;      // misses the world box: result -1 written below
-                                }
-                                result = 0;
-                            }
+                            active = false;      // misses the world box: result -1 written below
                         }
-                    }
-                    if (!has_ray) {                      // nothing to cast for this slot
-                        hit_triangle[slot] = result;
-                        hit_distance[slot] = 0.0f;
-                        if (result == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
                     }
                 }
             }
@@ -489,11 +470,11 @@ k_raycast_persistent(GeoView g, PhotonView pv, int first_photon, StepState *st, 
 
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK, RAY_WAVES) void
-k_raycast_wide(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue,
+k_raycast_wide(GeoView g, const float4 *rays, int first_photon, StepState *st,
                int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint2 *spill_base, DeviceCounters *counters,
                int big_chunk)
 {
-    const int nthreads = (int)st->n, renorm = (int)st->renorm;
+    const int nthreads = (int)st->n;
     if ((long long)blockIdx.x * PROP_BLOCK >= nthreads) return;
     uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
     // rays taken from the queue per atomic: many for big batches (a hot word serves only ~88 atomics/us),
@@ -544,39 +525,24 @@ k_raycast_wide(GeoView g, PhotonView pv, int first_photon, StepState *st, const 
             if (!has_ray) {
                 if (idx < loc_end) {
                     slot = first_photon + (int)idx;
-                    uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
-                    int result = HIT_SKIP;
-                    if (!(pv.flags[photon_id] & CHROMA_TERMINAL_MASK)) {
-                        origin = load3(pv.pos, photon_id);
-                        direction = load3(pv.dir, photon_id);
-                        if (renorm) direction = direction / norm(direction);
-                        if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
-                            result = HIT_NAN;
-                        } else {
-                            v3 noid = (-origin) / direction;
-                            v3 inv_dir = 1.0f / direction;
-                            bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
-                                            cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
-                            if (!moderate) {
-                                result = HIT_RETRY;
-                            } else {
-                                rf = ray_fast(g, noid, inv_dir);
-                                last_hit = pv.last_hit_dev[photon_id];
-                                triangle_index = -1;
-                                min_distance = -1.0f;
-                                sp = 0;
-                                npend = 0;
-                                cur = 0;                 // the wide root holds the children of the reference root
-                                has_ray = true;
-                                active = true;
-                                result = 0;
-                            }
-                        }
-                    }
-                    if (!has_ray) {
-                        hit_triangle[slot] = result;
-                        hit_distance[slot] = 0.0f;
-                        if (result == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
+                    const float4 *r = rays + 4 * (size_t)slot;
+                    const float4 r0 = r[0], r1 = r[1];
+                    if (__float_as_int(r1.w) == 0) {             // (other slots were settled by k_ray_setup)
+                        const float4 r2 = r[2], r3 = r[3];
+                        origin = mk3(r0.x, r0.y, r0.z);
+                        direction = mk3(r1.x, r1.y, r1.z);
+                        last_hit = __float_as_int(r0.w);
+                        rf.a = mk3(r2.x, r2.y, r2.z);
+                        const v3 bb = mk3(r3.x, r3.y, r3.z);
+                        rf.blo = bb - rf.a;
+                        rf.bhi = bb + rf.a;
+                        triangle_index = -1;
+                        min_distance = -1.0f;
+                        sp = 0;
+                        npend = 0;
+                        cur = 0;                 // the wide root holds the children of the reference root
+                        has_ray = true;
+                        active = true;
                     }
                 }
             }
@@ -1286,7 +1252,7 @@ __device__ inline int coop_cast(const GeoView &g, v3 origin, v3 direction, int l
 
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
-k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input_queue, uint32_t *output_queue,
+k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const float4 *work_in,
             uint64_t seed, uint64_t id_base, int max_steps, int use_weights, int scatter_first, uint2 *spill_base,
             DeviceCounters *counters)
 {
@@ -1311,25 +1277,25 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input
     cm_rng rng;
     State s;
     if (id < nthreads) {
-        photon_id = input_queue[id];
-        p.position = load3(pv.pos, photon_id);
-        p.direction = load3(pv.dir, photon_id);
-        p.polarization = load3(pv.pol, photon_id);
+        const float4 *w = work_in + 4 * (size_t)id;
+        const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        photon_id = __float_as_uint(w3.w);
+        p.position = mk3(w0.x, w0.y, w0.z);
+        p.direction = mk3(w1.x, w1.y, w1.z);
+        p.polarization = mk3(w2.x, w2.y, w2.z);
         if (renorm) {
             p.direction = p.direction / norm(p.direction);
             p.polarization = p.polarization / norm(p.polarization);
         }
-        p.wavelength = pv.wavelengths[photon_id];
-        p.time = pv.t[photon_id];
-        p.last_hit_triangle = pv.last_hit_triangles[photon_id];
-        last_hit_dev = pv.last_hit_dev[photon_id];
-        p.history = pv.flags[photon_id];
-        p.weight = pv.weights[photon_id];
-        p.evidx = pv.evidx[photon_id];
-        if (!(p.history & CHROMA_TERMINAL_MASK)) {
-            loaded = true;
-            cm_rng_init(&rng, seed, id_base + photon_id, pv.rng_counters[photon_id]);
-        }
+        p.wavelength = w0.w;
+        p.time = w1.w;
+        p.weight = w2.w;
+        p.history = __float_as_uint(w3.x);
+        last_hit_dev = __float_as_int(w3.z);
+        p.last_hit_triangle = last_hit_dev >= 0 ? (int)g.dev_to_tri[last_hit_dev] : -1;
+        p.evidx = 0;
+        loaded = true;                                      // (the working set holds live photons only)
+        cm_rng_init(&rng, seed, id_base + photon_id, __float_as_uint(w3.y));
     }
 
     bool live = loaded;
@@ -1375,8 +1341,7 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input
         }
     }
 
-    bool alive = false;
-    if (loaded && j == 0) {
+    if (loaded && j == 0) {                                 // the call ends with this kernel: everything goes back
         pv.rng_counters[photon_id] = rng.counter;
         store3(pv.pos, photon_id, p.position);
         store3(pv.dir, photon_id, p.direction);
@@ -1385,12 +1350,8 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input
         pv.t[photon_id] = p.time;
         pv.flags[photon_id] = p.history;
         pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
-        pv.last_hit_dev[photon_id] = last_hit_dev;
         pv.weights[photon_id] = p.weight;
-        pv.evidx[photon_id] = p.evidx;
-        alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
     }
-    if (output_queue) wave_queue_append(output_queue, alive, photon_id);
 
     if (COUNT) {
         unsigned long long sts = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
@@ -1407,21 +1368,20 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const uint32_t *input
 // They take the literal reference walk, intersect_mesh_strict.  ~1e-4 of the rays.
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
-k_raycast_retry(GeoView g, PhotonView pv, int first_photon, const StepState *st, const uint32_t *input_queue,
+k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
                 int32_t *hit_triangle, float *hit_distance, const uint32_t *retry_list, DeviceCounters *counters)
 {
-    const int nretry = (int)st->retry, renorm = (int)st->renorm;
+    const int nretry = (int)st->retry;
     __shared__ uint32_t s_lds[TRAV_LDS_WORDS(STACK_LDS, PROP_BLOCK)];
     if (nretry == 0) return;
     LaneCounters cnt = {0, 0, 0, 0};
     const int stride = gridDim.x * PROP_BLOCK;
     for (int k = blockIdx.x * PROP_BLOCK + threadIdx.x; k < nretry; k += stride) {      // lanes are independent here
         const int slot = (int)retry_list[k];
-        uint32_t photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
-        v3 position = load3(pv.pos, photon_id);
-        v3 direction = load3(pv.dir, photon_id);
-        if (renorm) direction = direction / norm(direction);
-        int last_hit = pv.last_hit_dev[photon_id];
+        const float4 *r = rays + 4 * (size_t)slot;
+        const float4 r0 = r[0], r1 = r[1];
+        v3 position = mk3(r0.x, r0.y, r0.z), direction = mk3(r1.x, r1.y, r1.z);          // (normalised by k_ray_setup)
+        int last_hit = __float_as_int(r0.w);
         float dist;
         int found = intersect_mesh_dev<STACK_LDS, PROP_BLOCK, COUNT>(g, position, direction, dist, last_hit, s_lds + threadIdx.x, cnt, true);
         hit_triangle[slot] = found;
@@ -1444,85 +1404,160 @@ k_raycast_retry(GeoView g, PhotonView pv, int first_photon, const StepState *st,
 #define PHYS_WAVES_PER_EU 4
 #endif
 __global__ __launch_bounds__(PHYS_BLOCK) __attribute__((amdgpu_waves_per_eu(PHYS_WAVES_PER_EU))) void
-k_physics(GeoView g, PhotonView pv, int first_photon, StepState *st, const uint32_t *input_queue, uint32_t *output_queue,
-          const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base, int use_weights,
-          int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters)
+k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32_t *output_queue, float4 *work_out,
+          const float4 *rays, const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base,
+          int use_weights, int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters)
 {
-    // Two passes per step.  Main pass (fixup = 0): every queue slot; a slot the ray cast handed to the
-    // strict walk (HIT_RETRY) is left alone, and so is a hit that is not REGULAR (record_hit_is_regular,
-    // propagate_device.h): its slot joins retry_list.  Fix-up pass (fixup = 1), after k_raycast_retry
-    // has walked those rays the reference's way: the listed slots only, results taken as they are.
+    // Two passes per step.  Main pass (fixup = 0): every slot of the working set; a slot the ray cast
+    // handed to the strict walk (HIT_RETRY) is left alone, and so is a hit that is not REGULAR
+    // (record_hit_is_regular, propagate_device.h): its slot joins retry_list.  Fix-up pass (fixup = 1),
+    // after k_raycast_retry has walked those rays the reference's way: the listed slots only, results
+    // taken as they are.  A photon that survives the step is appended to the next working set; one that
+    // ends here is written to the caller's arrays (the only time they are touched).
     __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
     const int nthreads = fixup ? (int)st->retry : (int)st->n, renorm = (int)st->renorm;
     unsigned long long nsteps = 0;
-    // the grid is sized for an upper bound of the photon count: blocks stride over the queue
+    // the grid is sized for an upper bound of the photon count: blocks stride over the slots
     for (int block_base = blockIdx.x * PHYS_BLOCK; block_base < nthreads; block_base += gridDim.x * PHYS_BLOCK) {
     int id = block_base + threadIdx.x;
     bool alive = false;
     uint32_t photon_id = 0;
+    Photon p;
+    uint32_t counter = 0;
+    int last_hit_record = -1;
     if (id < nthreads) {
-        const int slot = fixup ? (int)retry_list[id] : first_photon + id;
-        photon_id = input_queue ? input_queue[slot] : (uint32_t)slot;
+        const int slot = fixup ? (int)retry_list[id] : id;
         int tri = hit_triangle[slot];
         const float hit_dist = hit_distance[slot];
         if (!fixup && tri >= 0) {
-            // is the fast walk's winner one the reference is sure to find too?
-            v3 o = load3(pv.pos, photon_id), d = load3(pv.dir, photon_id);
-            if (renorm) d = d / norm(d);
+            // is the fast walk's winner one the reference is sure to find too?  (origin and direction as
+            // the ray cast saw them: the ray record)
+            const float4 *r = rays + 4 * (size_t)slot;
+            const float4 r0 = r[0], r1 = r[1];
             const float4 *t = g.tri + 3 * (size_t)tri;
-            if (!record_hit_is_regular(g, t[0], t[1], t[2], o, d, hit_dist)) {
+            if (!record_hit_is_regular(g, t[0], t[1], t[2], mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), hit_dist)) {
                 retry_list[atomicAdd(&st->retry, 1u)] = (uint32_t)slot;
                 tri = HIT_RETRY;
             }
         }
-        if (tri != HIT_SKIP && tri != HIT_RETRY) {
+        if (tri != HIT_RETRY) {
             if (tri != HIT_NAN) nsteps++;
-            Photon p;
-            p.position = load3(pv.pos, photon_id);
-            p.direction = load3(pv.dir, photon_id);
-            p.polarization = load3(pv.pol, photon_id);
+            const float4 *w = work_in + 4 * (size_t)slot;
+            const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            photon_id = __float_as_uint(w3.w);
+            p.position = mk3(w0.x, w0.y, w0.z);
+            p.direction = mk3(w1.x, w1.y, w1.z);
+            p.polarization = mk3(w2.x, w2.y, w2.z);
             if (renorm) {
                 p.direction = p.direction / norm(p.direction);
                 p.polarization = p.polarization / norm(p.polarization);
             }
-            p.wavelength = pv.wavelengths[photon_id];
-            p.time = pv.t[photon_id];
+            p.wavelength = w0.w;
+            p.time = w1.w;
+            p.weight = w2.w;
+            p.history = __float_as_uint(w3.x);
             p.last_hit_triangle = -1;                // (set by apply_hit_dev)
-            p.history = pv.flags[photon_id];
-            // evidx never changes; the weight only with weights on or a forced first scatter (photon.h:480-505)
-            const bool weight_live = use_weights || scatter_first;
-            p.weight = weight_live ? pv.weights[photon_id] : 1.0f;
             p.evidx = 0;
+            last_hit_record = __float_as_int(w3.z);
             cm_rng rng;
-            cm_rng_init(&rng, seed, id_base + photon_id, pv.rng_counters[photon_id]);
+            cm_rng_init(&rng, seed, id_base + photon_id, __float_as_uint(w3.y));
             if (tri == HIT_NAN) {
-                p.last_hit_triangle = pv.last_hit_triangles[photon_id];      // untouched (propagate.cu:270-273)
+                // the last hit stays what it was (propagate.cu:270-273)
+                p.last_hit_triangle = last_hit_record >= 0 ? (int)g.dev_to_tri[last_hit_record] : -1;
                 p.history |= CHROMA_NO_HIT | CHROMA_NAN_ABORT;
             } else {
                 State s;
                 apply_hit_dev(s, p, g, tri, hit_dist);
                 if (tri != -1) step_after_hit(p, s, rng, g, use_weights != 0, scatter_first);
                 // (a photon scattered or absorbed in the bulk forgets the triangle, photon.h:232,262,283)
-                pv.last_hit_dev[photon_id] = (p.last_hit_triangle < 0) ? -1 : tri;
+                last_hit_record = (p.last_hit_triangle < 0) ? -1 : tri;
             }
-            pv.rng_counters[photon_id] = rng.counter;
-            store3(pv.pos, photon_id, p.position);
-            store3(pv.dir, photon_id, p.direction);
-            store3(pv.pol, photon_id, p.polarization);
-            pv.wavelengths[photon_id] = p.wavelength;
-            pv.t[photon_id] = p.time;
-            pv.flags[photon_id] = p.history;
-            pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
-            if (weight_live) pv.weights[photon_id] = p.weight;
+            counter = rng.counter;
             alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
+            if (!alive) {
+                pv.rng_counters[photon_id] = counter;
+                store3(pv.pos, photon_id, p.position);
+                store3(pv.dir, photon_id, p.direction);
+                store3(pv.pol, photon_id, p.polarization);
+                pv.wavelengths[photon_id] = p.wavelength;
+                pv.t[photon_id] = p.time;
+                pv.flags[photon_id] = p.history;
+                pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
+                pv.weights[photon_id] = p.weight;
+            }
         }
     }
-    if (output_queue) block_queue_append<PHYS_BLOCK / WAVE>(output_queue, alive, photon_id, s_counts);
+    const uint32_t at = block_queue_append<PHYS_BLOCK / WAVE>(output_queue, alive, photon_id, s_counts);
+    if (alive) {
+        float4 *w = work_out + 4 * (size_t)(at - 1u);
+        w[0] = make_float4(p.position.x, p.position.y, p.position.z, p.wavelength);
+        w[1] = make_float4(p.direction.x, p.direction.y, p.direction.z, p.time);
+        w[2] = make_float4(p.polarization.x, p.polarization.y, p.polarization.z, p.weight);
+        w[3] = make_float4(__uint_as_float(p.history), __uint_as_float(counter), __int_as_float(last_hit_record), __uint_as_float(photon_id));
+    }
     __syncthreads();        // s_counts is reused by the next round
     }
     if (counters) {
         nsteps = wave_sum_u64(nsteps);
         if (lane_id() == 0 && nsteps) atomicAdd(&counters->photon_steps, nsteps);
+    }
+}
+
+// ---- the dense working set ----------------------------------------------------------------------------
+// While a batch propagates, its live photons are kept as 64-byte records ordered by queue slot:
+// {pos, wavelength} {dir, time} {pol, weight} {flags, draw counter, last hit record, photon id}.  Steps
+// read and append these records (streaming), so their traffic follows the number of survivors; the
+// caller's SoA arrays are read once (here) and written once per photon (when it ends, or at the end of
+// the call).  Working through the arrays instead made steps 2..5 touch nearly every line of every array
+// for a fraction of the photons.
+// k_load_working also is the initial queue of GPUPhotons.propagate (chroma/gpu/photon.py:206-216: the
+// ncopies clones of a photon next to each other); photons that are already terminal are left out -- and
+// thereby untouched (propagate.cu:258).
+__global__ __launch_bounds__(PHYS_BLOCK) void
+k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t n, uint32_t ncopies, uint32_t true_n)
+{
+    __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
+    for (uint64_t block_base = (uint64_t)blockIdx.x * PHYS_BLOCK; block_base < n; block_base += (uint64_t)gridDim.x * PHYS_BLOCK) {
+        uint64_t j = block_base + threadIdx.x;
+        bool take = false;
+        uint32_t photon_id = 0, flags = 0;
+        if (j < n) {
+            photon_id = (uint32_t)(j / ncopies) + (uint32_t)(j % ncopies) * true_n;
+            flags = pv.flags[photon_id];
+            take = (flags & CHROMA_TERMINAL_MASK) == 0;
+        }
+        const uint32_t at = block_queue_append<PHYS_BLOCK / WAVE>(queue, take, photon_id, s_counts);
+        if (take) {
+            v3 pos = load3(pv.pos, photon_id), dir = load3(pv.dir, photon_id), pol = load3(pv.pol, photon_id);
+            int lh = pv.last_hit_triangles[photon_id];
+            lh = (lh >= 0 && (uint32_t)lh < g.ntriangles) ? (int)g.tri_to_dev[lh] : -1;
+            float4 *w = work + 4 * (size_t)(at - 1u);
+            w[0] = make_float4(pos.x, pos.y, pos.z, pv.wavelengths[photon_id]);
+            w[1] = make_float4(dir.x, dir.y, dir.z, pv.t[photon_id]);
+            w[2] = make_float4(pol.x, pol.y, pol.z, pv.weights[photon_id]);
+            w[3] = make_float4(__uint_as_float(flags), __uint_as_float(pv.rng_counters[photon_id]), __int_as_float(lh), __uint_as_float(photon_id));
+        }
+        __syncthreads();
+    }
+}
+// the photons still alive when the call ends go back to the caller's arrays
+__global__ void k_store_working(GeoView g, PhotonView pv, const uint32_t *queue, const float4 *work)
+{
+    const uint32_t n = queue[0] - 1u;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
+        const float4 *w = work + 4 * (size_t)slot;
+        const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        const uint32_t photon_id = __float_as_uint(w3.w);
+        const int rec = __float_as_int(w3.z);
+        store3(pv.pos, photon_id, mk3(w0.x, w0.y, w0.z));
+        store3(pv.dir, photon_id, mk3(w1.x, w1.y, w1.z));
+        store3(pv.pol, photon_id, mk3(w2.x, w2.y, w2.z));
+        pv.wavelengths[photon_id] = w0.w;
+        pv.t[photon_id] = w1.w;
+        pv.weights[photon_id] = w2.w;
+        pv.flags[photon_id] = __float_as_uint(w3.x);
+        pv.rng_counters[photon_id] = __float_as_uint(w3.y);
+        pv.last_hit_triangles[photon_id] = rec >= 0 ? (int)g.dev_to_tri[rec] : -1;
     }
 }
 
@@ -1541,15 +1576,6 @@ __global__ void k_init_queue(uint32_t *queue, uint64_t n, uint32_t ncopies, uint
 
 __global__ void k_set_word(uint32_t *p, uint32_t v) { *p = v; }
 
-// last_hit_triangles (triangle ids, API array) -> record indices for the step kernels
-__global__ void k_last_hit_to_records(const int32_t *last_hit_triangles, const uint32_t *tri_to_dev, int32_t *last_hit_dev,
-                                      uint64_t n, uint32_t ntriangles)
-{
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int32_t t = last_hit_triangles[i];
-    last_hit_dev[i] = (t >= 0 && (uint32_t)t < ntriangles) ? (int32_t)tri_to_dev[t] : -1;
-}
 
 // OR of (flags & mask) over all photons -> one word (abort warning, photon.py:254)
 __global__ void k_flags_or(const uint32_t *flags, uint64_t n, uint32_t mask, uint32_t *out)
@@ -1815,7 +1841,6 @@ static PhotonView to_view(const chroma_photon_arrays *a)
     PhotonView v;
     v.pos = a->pos; v.dir = a->dir; v.pol = a->pol; v.wavelengths = a->wavelengths; v.t = a->t;
     v.flags = a->flags; v.last_hit_triangles = a->last_hit_triangles; v.weights = a->weights;
-    v.last_hit_dev = nullptr;
     v.evidx = a->evidx; v.rng_counters = a->rng_counters;
     return v;
 }
@@ -1857,12 +1882,14 @@ static int launch_propagate(chroma_ctx *ctx, chroma_geometry *geom, PhotonView p
 }
 
 // one step for many photons: ray cast and physics as two launches
-// One step as ray cast + retry pass + physics, all reading the photon count and the launch policy
-// from ctx->d_step (k_step_begin).  `n_upper` bounds the count and sizes the grids; `in_q`/`out_q`
-// are whole queues (slot 0 = tail).  With `ev` (4 events): [0] step start, [3] ray-cast kernel start,
-// [1] its end, [2] step end.
+// One step as ray set-up + ray cast + physics (+ the strict walk and the physics of the few rays that
+// need it), all reading the photon count and the launch policy from ctx->d_step (k_step_begin).
+// `n_upper` bounds the count and sizes the grids; `in_q`/`out_q` are whole queues (slot 0 = tail) and
+// `work_in`/`work_out` the working sets that go with them.  With `ev` (4 events): [0] step start,
+// [3] ray-cast kernel start, [1] its end, [2] step end.
 static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, long long n_upper, const uint32_t *in_q,
-                             uint32_t *out_q, chroma_rng rng, int use_weights, int scatter_first, hipEvent_t *ev = nullptr)
+                             uint32_t *out_q, const float4 *work_in, float4 *work_out, chroma_rng rng, int use_weights,
+                             int scatter_first, hipEvent_t *ev = nullptr)
 {
     if (n_upper <= 0) return CHROMA_OK;
     uint32_t need = geom->stack_need;
@@ -1872,7 +1899,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     const bool quad = ctx->wide_walk == CHROMA_WALK_QUAD && have_wide && geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
     const bool coop = !quad && (ctx->wide_walk == CHROMA_WALK_COOP || ctx->wide_walk == CHROMA_WALK_QUAD) && have_wide &&
                       geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
-    const bool wide = !coop && ctx->wide_walk != CHROMA_WALK_REFERENCE && have_wide && geom->wide_stack_need <= WIDE_STACK + WIDE_SPILL;
+    const bool wide = !coop && !quad && ctx->wide_walk != CHROMA_WALK_REFERENCE && have_wide && geom->wide_stack_need <= WIDE_STACK + WIDE_SPILL;
     if (wide && !ctx->wide_spill) {
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipMalloc((void **)&ctx->wide_spill, (size_t)ctx->wide_waves * WIDE_SPILL * PROP_BLOCK * sizeof(uint2)));
@@ -1888,14 +1915,13 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
                                                           (long long)(wide ? ctx->wide_waves : ctx->persistent_waves));
     dim3 grid(waves), block(PROP_BLOCK);
     StepState *st = ctx->d_step;
-    const uint32_t *q = in_q + 1;
     // (with weights the reference runs ALL steps in one launch: every count is "few")
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st,
                        use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8));
     if (ev) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-    if (quad || coop) {
+    {
         unsigned sblocks = (unsigned)std::min<long long>((n_upper + 255) / 256, (long long)ctx->physics_blocks * 4);
-        hipLaunchKernelGGL(k_ray_setup, dim3(sblocks), dim3(256), 0, ctx->stream, geom->view, pv, st, q, ctx->rays,
+        hipLaunchKernelGGL(k_ray_setup, dim3(sblocks), dim3(256), 0, ctx->stream, geom->view, work_in, st, ctx->rays,
                            ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, &st->retry);
     }
     if (ev) HIP_TRY(hipEventRecord(ev[3], ctx->stream));        // the ray-cast kernel proper is timed from here
@@ -1908,10 +1934,10 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
             hipLaunchKernelGGL((k_raycast_coop<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
         else if (wide)                                                                                                 \
-            hipLaunchKernelGGL((k_raycast_wide<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,          \
+            hipLaunchKernelGGL((k_raycast_wide<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->wide_spill, ctx->d_counters, ctx->ray_chunk); \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_raycast_persistent<COUNT>), grid, block, 0, ctx->stream, geom->view, pv, 0, st, q,    \
+            hipLaunchKernelGGL((k_raycast_persistent<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st, \
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);                \
         if (ev) HIP_TRY(hipEventRecord(ev[1], ctx->stream));                                                            \
     } while (0)
@@ -1920,18 +1946,18 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     // physics for every slot whose hit is regular; then the strict walk and the physics of the rest
     unsigned pblocks = (unsigned)std::min<long long>((n_upper + PHYS_BLOCK - 1) / PHYS_BLOCK, (long long)ctx->physics_blocks);
     DeviceCounters *pc = ctx->counting ? ctx->d_counters : nullptr;
-    hipLaunchKernelGGL(k_physics, dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, 0, st,
-                       q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
+    hipLaunchKernelGGL(k_physics, dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
+                       ctx->rays, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
                        ctx->retry_list, 0, pc);
     if (ctx->counting)
-        hipLaunchKernelGGL((k_raycast_retry<true>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, st, q,
+        hipLaunchKernelGGL((k_raycast_retry<true>), dim3(256), block, 0, ctx->stream, geom->view, ctx->rays, st,
                            ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
     else
-        hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, pv, 0, st, q,
+        hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, ctx->rays, st,
                            ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
-    hipLaunchKernelGGL(k_physics, dim3(std::min(pblocks, 64u)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, 0, st,
-                       q, out_q, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                       ctx->retry_list, 1, pc);
+    hipLaunchKernelGGL(k_physics, dim3(std::min(pblocks, 64u)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
+                       work_out, ctx->rays, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
+                       scatter_first, ctx->retry_list, 1, pc);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
@@ -1940,7 +1966,8 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
 // All remaining steps of the last photons in one launch (k_tail_coop).  Returns CHROMA_OK and sets
 // *done when the geometry has a wide tree the kernel can walk; otherwise leaves *done false.
 static int launch_tail(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, long long n_upper, const uint32_t *in_q,
-                       uint32_t *out_q, chroma_rng rng, int nsteps, int use_weights, int scatter_first, hipEvent_t *ev, bool *done)
+                       uint32_t *out_q, const float4 *work_in, chroma_rng rng, int nsteps, int use_weights, int scatter_first,
+                       hipEvent_t *ev, bool *done)
 {
     *done = false;
     if (!geom->view.wnodes || geom->wide_stack_need > COOP_STACK + COOP_SPILL || geom->stack_need > STACK_LDS + STACK_SCRATCH)
@@ -1956,10 +1983,10 @@ static int launch_tail(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, lo
                        use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8));
     if (ev) { HIP_TRY(hipEventRecord(ev[0], ctx->stream)); HIP_TRY(hipEventRecord(ev[1], ctx->stream)); }
     if (ctx->counting)
-        hipLaunchKernelGGL((k_tail_coop<true>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, in_q + 1, out_q,
+        hipLaunchKernelGGL((k_tail_coop<true>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in,
                            rng.seed, rng.photon_id_base, nsteps, use_weights, scatter_first, ctx->coop_spill, ctx->d_counters);
     else
-        hipLaunchKernelGGL((k_tail_coop<false>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, in_q + 1, out_q,
+        hipLaunchKernelGGL((k_tail_coop<false>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in,
                            rng.seed, rng.photon_id_base, nsteps, use_weights, scatter_first, ctx->coop_spill, ctx->d_counters);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(hipGetLastError());
@@ -2178,9 +2205,10 @@ int chroma_shutdown(chroma_ctx *ctx)
     for (hipEvent_t e : ctx->step_events) hipEventDestroy(e);
     if (ctx->hit_triangle) hipFree(ctx->hit_triangle);
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
-    if (ctx->last_hit_dev) hipFree(ctx->last_hit_dev);
     if (ctx->retry_list) hipFree(ctx->retry_list);
     if (ctx->rays) hipFree(ctx->rays);
+    if (ctx->work_a) hipFree(ctx->work_a);
+    if (ctx->work_b) hipFree(ctx->work_b);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_words);
     hipHostFree(ctx->h_words);
@@ -2701,20 +2729,23 @@ static int ensure_queues(chroma_ctx *ctx, size_t n)
     if (ctx->queue_b) hipFree(ctx->queue_b);
     if (ctx->hit_triangle) hipFree(ctx->hit_triangle);
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
-    if (ctx->last_hit_dev) hipFree(ctx->last_hit_dev);
     if (ctx->retry_list) hipFree(ctx->retry_list);
     if (ctx->rays) hipFree(ctx->rays);
+    if (ctx->work_a) hipFree(ctx->work_a);
+    if (ctx->work_b) hipFree(ctx->work_b);
+    ctx->work_a = ctx->work_b = nullptr;
     ctx->queue_a = ctx->queue_b = nullptr;
-    ctx->hit_triangle = nullptr; ctx->hit_distance = nullptr; ctx->last_hit_dev = nullptr; ctx->retry_list = nullptr;
+    ctx->hit_triangle = nullptr; ctx->hit_distance = nullptr; ctx->retry_list = nullptr;
     ctx->rays = nullptr;
     ctx->queue_capacity = 0;
     HIP_TRY(hipMalloc((void **)&ctx->queue_a, (n + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->queue_b, (n + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->hit_triangle, (n + 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->hit_distance, (n + 1) * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&ctx->last_hit_dev, (n + 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->retry_list, (n + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->rays, (n + 1) * 4 * sizeof(float4)));
+    HIP_TRY(hipMalloc((void **)&ctx->work_a, (n + 1) * 4 * sizeof(float4)));
+    HIP_TRY(hipMalloc((void **)&ctx->work_b, (n + 1) * 4 * sizeof(float4)));
     ctx->queue_capacity = n + 1;
     return CHROMA_OK;
 }
@@ -2762,36 +2793,36 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     HIP_TRY(hipSetDevice(ctx->device));
     rc = ensure_queues(ctx, nphotons); if (rc) return rc;
     PhotonView pv = to_view(photons);
-    pv.last_hit_dev = ctx->last_hit_dev;
-    hipLaunchKernelGGL(k_last_hit_to_records, dim3((unsigned)((nphotons + 255) / 256)), dim3(256), 0, ctx->stream,
-                       photons->last_hit_triangles, geom->view.tri_to_dev, ctx->last_hit_dev, (uint64_t)nphotons,
-                       geom->view.ntriangles);
     uint32_t *in_q = ctx->queue_a, *out_q = ctx->queue_b;
-
-    hipLaunchKernelGGL(k_init_queue, dim3((unsigned)((nphotons + 255) / 256)), dim3(256), 0, ctx->stream, in_q,
-                       (uint64_t)nphotons, ncopies, (uint32_t)(nphotons / ncopies));
-    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, out_q, 1u);
-    HIP_TRY(hipGetLastError());
+    float4 *work_in = ctx->work_a, *work_out = ctx->work_b;
 
     double kernel_ms = 0.0, raycast_ms = 0.0;
     uint64_t launches = 0, raycast_launches = 0;
     // Launch policy of the reference (chroma/gpu/photon.py:225-252): one step per launch while many
     // photons are alive, and ONE launch for all remaining steps once fewer than 64*16*8 are left (or
     // with weights).  A launch re-normalises dir/pol when it loads a photon (propagate.cu:248,250), so
-    // the policy is part of the arithmetic.  Without weights every step here is a ray cast + physics
-    // pair that gets the whole chip; a step that the reference would run inside its last launch skips
-    // the re-normalisation instead (same numbers; with weights that is every step but the first).  The
-    // policy is evaluated ON THE DEVICE
-    // (k_step_begin), so the steps are enqueued back to back; the host looks at the survivor count
-    // only now and then, to stop early and to shrink the grids.
+    // the policy is part of the arithmetic.  Here every step is a ray cast + physics pair that gets the
+    // whole chip; a step that the reference would run inside its last launch skips the re-normalisation
+    // instead (same numbers; with weights that is every step but the first).  The policy is evaluated ON
+    // THE DEVICE (k_step_begin), so the steps are enqueued back to back; the host looks at the survivor
+    // count only now and then, to stop early, to shrink the grids and to hand the last photons to the
+    // fused tail kernel.  The live photons travel in the dense working set (k_load_working).
     const bool device_steps = ctx->split_tail != 0;
     if (device_steps) {
         HIP_TRY(hipMemsetAsync(ctx->d_step, 0, sizeof(StepState), ctx->stream));
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, in_q, 1u);
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, out_q, 1u);
+        {
+            unsigned blocks = (unsigned)std::min<uint64_t>((nphotons + PHYS_BLOCK - 1) / PHYS_BLOCK, (uint64_t)ctx->physics_blocks);
+            hipLaunchKernelGGL(k_load_working, dim3(blocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, in_q, work_in,
+                               (uint64_t)nphotons, ncopies, (uint32_t)(nphotons / ncopies));
+        }
+        HIP_TRY(hipGetLastError());
         const int nev = time_kernels ? 4 * max_steps : 0;
         while ((int)ctx->step_events.size() < nev) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->step_events.push_back(e); }
         long long n_upper = (long long)nphotons;
         int step = 0, next_check = 1, steps_timed = 0;
-        bool done = false;
+        bool done = false, tail_done = false;
         const long long few = (long long)PROP_BLOCK * 16 * 8;
         const bool fused_tail = ctx->fused_tail && (ctx->wide_walk == CHROMA_WALK_COOP || ctx->wide_walk == CHROMA_WALK_QUAD);    // (the cross-check walks keep per-step launches)
         int tail_step = -1;                  // the step at which the fused tail was launched
@@ -2799,21 +2830,23 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
             if (fused_tail && n_upper < few) {
                 // the reference's last launch: all remaining steps at once, 8 lanes per photon
                 bool launched = false;
-                rc = launch_tail(ctx, geom, pv, n_upper, in_q, out_q, rng, max_steps - step, use_weights, step == 0 ? scatter_first : 0,
-                                 time_kernels ? ctx->step_events.data() + 4 * step : nullptr, &launched);
+                rc = launch_tail(ctx, geom, pv, n_upper, in_q, out_q, work_in, rng, max_steps - step, use_weights,
+                                 step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 4 * step : nullptr, &launched);
                 if (rc) return rc;
                 if (launched) {
                     if (time_kernels) { tail_step = step; steps_timed = step + 1; }
                     step = max_steps;
+                    tail_done = true;            // (it wrote every photon it held back to the caller's arrays)
                     break;
                 }
             }
-            rc = launch_split_step(ctx, geom, pv, n_upper, in_q, out_q, rng, use_weights, step == 0 ? scatter_first : 0,
-                                   time_kernels ? ctx->step_events.data() + 4 * step : nullptr);
+            rc = launch_split_step(ctx, geom, pv, n_upper, in_q, out_q, work_in, work_out, rng, use_weights,
+                                   step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 4 * step : nullptr);
             if (rc) return rc;
             if (time_kernels) steps_timed = step + 1;
             step++;
             std::swap(in_q, out_q);
+            std::swap(work_in, work_out);
             if (step == next_check && step < max_steps) {
                 // survivors = tail - 1 of what is now the input queue
                 HIP_TRY(hipMemcpyAsync(ctx->h_words + 1, in_q, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2823,6 +2856,11 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                 // look every step once the tail is near, so that it starts when the reference's does
                 next_check = (fused_tail && n_upper < 16 * few) ? step + 1 : (step < 8) ? step * 2 : step + 8;
             }
+        }
+        if (!tail_done && !done) {
+            // max_steps reached with photons still alive: they go back to the caller's arrays
+            unsigned blocks = (unsigned)std::min<long long>((n_upper + 255) / 256, 4096);
+            hipLaunchKernelGGL(k_store_working, dim3(std::max(blocks, 1u)), dim3(256), 0, ctx->stream, geom->view, pv, in_q, work_in);
         }
         HIP_TRY(hipMemcpyAsync(ctx->h_step, ctx->d_step, sizeof(StepState), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -2837,18 +2875,18 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
             raycast_launches++;
         }
     } else {
+        // CHROMA_TAIL=fused: the lane-per-photon kernel with the reference's own launch shapes
+        hipLaunchKernelGGL(k_init_queue, dim3((unsigned)((nphotons + 255) / 256)), dim3(256), 0, ctx->stream, in_q,
+                           (uint64_t)nphotons, ncopies, (uint32_t)(nphotons / ncopies));
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, out_q, 1u);
+        HIP_TRY(hipGetLastError());
         uint64_t n = nphotons;
         int step = 0;
         while (step < max_steps) {
             const bool few = n < (uint64_t)PROP_BLOCK * 16 * 8;
             int nsteps = (few || use_weights) ? (max_steps - step) : 1;
             if (time_kernels) HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-            if (nsteps == 1) {
-                HIP_TRY(hipMemsetAsync(ctx->d_step, 0, sizeof(StepState), ctx->stream));      // not in the tail: re-normalise
-                rc = launch_split_step(ctx, geom, pv, (long long)n, in_q, out_q, rng, use_weights, scatter_first);
-            } else {
-                rc = launch_propagate(ctx, geom, pv, 0, (int)n, in_q + 1, out_q, rng, nsteps, use_weights, scatter_first);
-            }
+            rc = launch_propagate(ctx, geom, pv, 0, (int)n, in_q + 1, out_q, rng, nsteps, use_weights, scatter_first);
             if (rc) return rc;
             launches++;
             if (time_kernels) {

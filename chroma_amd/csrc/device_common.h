@@ -81,10 +81,6 @@ struct GeoView {
 struct PhotonView {   // device pointers of chroma_photon_arrays
     float *pos, *dir, *pol, *wavelengths, *t;
     uint32_t *flags; int32_t *last_hit_triangles; float *weights; uint32_t *evidx; uint32_t *rng_counters;
-    // internal to chroma_propagate: last_hit_triangles as triangle RECORD indices, kept beside the
-    // API array so that no step has to translate through tri_to_dev / dev_to_tri (three 128-B lines
-    // per photon step for 12 bytes)
-    int32_t *last_hit_dev;
 };
 
 struct DeviceCounters {   // accumulated with one atomic per wave
@@ -115,7 +111,7 @@ __device__ inline void wave_queue_append(uint32_t *queue, bool pred, uint32_t va
 // wave is too many for 1e8 photons).  Waves publish their counts in LDS, wave 0 reserves the
 // block's span, every lane then writes at its own offset.  All threads of the block must call it.
 template <int MAX_WAVES>
-__device__ inline void block_queue_append(uint32_t *queue, bool pred, uint32_t value, uint32_t *s_counts /* [MAX_WAVES+1] */)
+__device__ inline uint32_t block_queue_append(uint32_t *queue, bool pred, uint32_t value, uint32_t *s_counts /* [MAX_WAVES+1] */)
 {
     unsigned long long mask = __ballot(pred);
     unsigned lane = lane_id();
@@ -128,10 +124,12 @@ __device__ inline void block_queue_append(uint32_t *queue, bool pred, uint32_t v
         s_counts[MAX_WAVES] = total ? atomicAdd(queue, total) : 0u;
     }
     __syncthreads();
+    uint32_t at = 0;                       // position in the queue (>= 1) of this lane's entry, 0 if none
     if (pred) {
-        uint32_t base = s_counts[MAX_WAVES] + s_counts[wave];
-        queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+        at = s_counts[MAX_WAVES] + s_counts[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        queue[at] = value;
     }
+    return at;
 }
 
 __device__ inline unsigned long long wave_sum_u64(unsigned long long v)
