@@ -914,6 +914,29 @@ __device__ inline uint32_t quad_max_u32(uint32_t v)
     return v;
 }
 
+// box_interval_fast with the two faces of an axis as one packed operation (v_pk_fma_f32: same fused
+// multiply-add per half, half the issue slots)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ inline void box_interval_pk(const v3 &a, f32x2 bx, f32x2 by, f32x2 bz, uint4 nd, float &tmin, float &tmax)
+{
+    f32x2 qx = {(float)(nd.x & 0xFFFFu), (float)(nd.x >> 16)};
+    f32x2 qy = {(float)(nd.y & 0xFFFFu), (float)(nd.y >> 16)};
+    f32x2 qz = {(float)(nd.z & 0xFFFFu), (float)(nd.z >> 16)};
+    const f32x2 tx = __builtin_elementwise_fma(qx, (f32x2){a.x, a.x}, bx);
+    const f32x2 ty = __builtin_elementwise_fma(qy, (f32x2){a.y, a.y}, by);
+    const f32x2 tz = __builtin_elementwise_fma(qz, (f32x2){a.z, a.z}, bz);
+    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)),
+                           __builtin_fmaxf(__builtin_fminf(tz.x, tz.y), 0.0f));
+    tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)),
+                           __builtin_fmaxf(tz.x, tz.y));
+}
+__device__ inline uint32_t quad_or_u32(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+    return v;
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD_WAVES_PER_EU, QUAD_WAVES_PER_EU))) void
 k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
@@ -929,10 +952,10 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     __shared__ uint32_t s_lds[16 * QUAD_STRIDE];
     const unsigned lane = lane_id();
     const unsigned j = lane & 3u, gshift = lane & ~3u, grp = lane >> 2;
-    const uint32_t below = (1u << j) - 1u;
-    // this quad's 4 bits of a 64-bit ballot, without a 64-bit shift (quarter rate): pick the half, extract
-    const uint32_t upper_mask = lane >= 32u ? 0xFFFFFFFFu : 0u, bshift = gshift & 31u;
-#define QUAD_BITS(m) __builtin_amdgcn_ubfe((((uint32_t)((m) >> 32)) & upper_mask) | (((uint32_t)(m)) & ~upper_mask), bshift, 4u)
+    // what the 4 lanes of a quad decide about their 8 entries travels as ONE word, OR-ed across the quad
+    // by two DPP steps: bit j of nibble 0/1 = lane j's first/second entry is a leaf to test, of nibble
+    // 2/3 = it is an inner node to visit.  (Wave ballots cost two VALU operations each plus the extract.)
+    const uint32_t jbit = 1u << j, below2 = (jbit - 1u) * 0x11u;
     uint32_t *stack_n = s_lds + grp * QUAD_STRIDE;
     float *stack_t = (float *)(stack_n + COOP_STACK);
     uint32_t *pending = stack_n + 2 * COOP_STACK;
@@ -943,8 +966,8 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     bool has_ray = false, active = false;
     int slot = 0;
     v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
-    RayFast rf;
-    rf.a = rf.blo = rf.bhi = mk3(0.f, 0.f, 0.f);
+    v3 ra = mk3(0.f, 0.f, 0.f);             // RayFast::a, and {blo, bhi} per axis
+    f32x2 rbx = {0.f, 0.f}, rby = {0.f, 0.f}, rbz = {0.f, 0.f};
     uint32_t last_hit_w = WIDE_NONE;        // the leaf word of the photon's last hit (never entered)
     int triangle_index = -1;
     uint32_t best_rank = 0;
@@ -981,10 +1004,10 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     origin = mk3(r0.x, r0.y, r0.z);
                     direction = mk3(r1.x, r1.y, r1.z);
                     { const int lh = __float_as_int(r0.w); last_hit_w = lh >= 0 ? (0x80000000u | (uint32_t)lh) : WIDE_NONE; }
-                    rf.a = mk3(r2.x, r2.y, r2.z);
-                    const v3 bb = mk3(r3.x, r3.y, r3.z);
-                    rf.blo = bb - rf.a;
-                    rf.bhi = bb + rf.a;
+                    ra = mk3(r2.x, r2.y, r2.z);
+                    rbx = (f32x2){r3.x - ra.x, r3.x + ra.x};
+                    rby = (f32x2){r3.y - ra.y, r3.y + ra.y};
+                    rbz = (f32x2){r3.z - ra.z, r3.z + ra.z};
                     triangle_index = -1;
                     min_distance = -1.0f;
                     prune_t = cm_inff();
@@ -1021,25 +1044,26 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 const uint4 ea = np[0], eb = np[1];
                 if (COUNT && j == 0) cnt.nodes += 8;
                 float ta, tb, fa, fb;
-                box_interval_fast(rf, ea, ta, fa);
-                box_interval_fast(rf, eb, tb, fb);
+                box_interval_pk(ra, rbx, rby, rbz, ea, ta, fa);
+                box_interval_pk(ra, rbx, rby, rbz, eb, tb, fb);
                 // intersect_node (mesh.h:16-34) with prune_t = +inf until something is hit
                 const bool pa = (ea.w != WIDE_NONE) & !(ta > fa) & !(ta > prune_t);
                 const bool pb = (eb.w != WIDE_NONE) & !(tb > fb) & !(tb > prune_t);
                 const bool la = pa & ((int)ea.w < 0) & (ea.w != last_hit_w);
                 const bool lb = pb & ((int)eb.w < 0) & (eb.w != last_hit_w);
                 const bool ia = pa & ((int)ea.w >= 0), ib = pb & ((int)eb.w >= 0);
-                const uint32_t mla = QUAD_BITS(__ballot(la)), mlb = QUAD_BITS(__ballot(lb));
-                const uint32_t mia = QUAD_BITS(__ballot(ia)), mib = QUAD_BITS(__ballot(ib));
+                const uint32_t qm = quad_or_u32((((((ib ? jbit : 0u) << 4) | (ia ? jbit : 0u)) << 4 | (lb ? jbit : 0u)) << 4) |
+                                                (la ? jbit : 0u));
                 // postponed triangles: ring slots after the ones already there, lower lanes first
                 {
-                    uint32_t off = phead + (uint32_t)npend + __popc(mla & below) + __popc(mlb & below);
+                    uint32_t off = phead + (uint32_t)npend + __popc(qm & below2);
                     if (la) pending[off & (QUAD_PENDING - 1u)] = ea.w & 0x7FFFFFFFu;
                     if (lb) pending[(off + (la ? 1u : 0u)) & (QUAD_PENDING - 1u)] = eb.w & 0x7FFFFFFFu;
-                    npend += __popc(mla) + __popc(mlb);
+                    npend += __popc(qm & 0xFFu);
                 }
                 cur = WIDE_NONE;
-                if (mia | mib) {
+                const uint32_t mi = qm >> 8;                 // inner entries: nibble 0 = first, nibble 1 = second entries
+                if (mi) {
                     // nearest inner child: smallest (distance, entry) key -- the entry number replaces
                     // the low 3 mantissa bits, which only matters for the ORDER of the visits
                     const uint32_t ka = ia ? ((__float_as_uint(ta) & ~7u) | (2u * j)) : 0xFFFFFFFFu;
@@ -1049,9 +1073,8 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     cur = quad_max_u32(na ? ea.w : (nb ? eb.w : 0u));
                     // every other inner child goes on the stack at its own slot
                     const bool qa = ia && !na, qb = ib && !nb;
-                    const uint32_t moa = mia & ~((ne & 1u) ? 0u : (1u << (ne >> 1)));
-                    const uint32_t mob = mib & ~((ne & 1u) ? (1u << (ne >> 1)) : 0u);
-                    int pos = sp + __popc(moa & below) + __popc(mob & below);
+                    const uint32_t mo = mi & ~(1u << ((ne >> 1) | ((ne & 1u) << 2)));
+                    int pos = sp + __popc(mo & below2);
                     if (qa) {
                         if (pos < COOP_STACK) { stack_n[pos] = ea.w; stack_t[pos] = ta; }
                         else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(ea.w, __float_as_uint(ta));
@@ -1061,7 +1084,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                         if (pos < COOP_STACK) { stack_n[pos] = eb.w; stack_t[pos] = tb; }
                         else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(eb.w, __float_as_uint(tb));
                     }
-                    sp += __popc(moa) + __popc(mob);
+                    sp += __popc(mo);
                     if (sp > COOP_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
                         triangle_index = HIT_RETRY;
                         active = false; npend = 0; cur = WIDE_NONE; sp = 0;
@@ -1117,7 +1140,6 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
         }
     }
 
-#undef QUAD_BITS
     if (COUNT) {
         unsigned long long nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
         if (lane == 0) {
