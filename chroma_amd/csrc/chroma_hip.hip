@@ -413,7 +413,7 @@ k_raycast_persistent(GeoView g, const float4 *rays, int first_photon, StepState 
             if (j < npend) {
                 uint32_t tri = pending[j * PROP_BLOCK];
                 if (COUNT) cnt.tris++;
-                const float4 *t = g.tri + 3 * (size_t)tri;
+                const float4 *t = g.tri + TRI_STRIDE * (size_t)tri;
                 float4 a = t[0], b = t[1], c = t[2];
                 float distance;
                 if (intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance)) {
@@ -614,7 +614,7 @@ k_raycast_wide(GeoView g, const float4 *rays, int first_photon, StepState *st,
             if (j < npend) {
                 uint32_t tri = pending[j * PROP_BLOCK];
                 if (COUNT) cnt.tris++;
-                const float4 *t = g.tri + 3 * (size_t)tri;
+                const float4 *t = g.tri + TRI_STRIDE * (size_t)tri;
                 float4 a = t[0], b = t[1], cc = t[2];
                 float distance;
                 if (intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), distance)) {
@@ -834,7 +834,7 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 if ((int)j < take) {
                     tri = pending[j];
                     if (COUNT) cnt.tris++;
-                    const float4 *tp = g.tri + 3 * (size_t)tri;
+                    const float4 *tp = g.tri + TRI_STRIDE * (size_t)tri;
                     float4 a = tp[0], b = tp[1], c = tp[2];
                     hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
                     rank = __float_as_uint(c.w);
@@ -1104,7 +1104,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 if ((int)j < take) {
                     tri = pending[(phead + j) & (QUAD_PENDING - 1u)];
                     if (COUNT) cnt.tris++;
-                    const float4 *tp = g.tri + 3 * (size_t)tri;
+                    const float4 *tp = g.tri + TRI_STRIDE * (size_t)tri;
                     float4 a = tp[0], b = tp[1], c = tp[2];
                     hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
                     rank = __float_as_uint(c.w);
@@ -1242,7 +1242,7 @@ __device__ inline int coop_cast(const GeoView &g, v3 origin, v3 direction, int l
                 if ((int)j < take) {
                     tri = pending[j];
                     if (COUNT) cnt.tris++;
-                    const float4 *tp = g.tri + 3 * (size_t)tri;
+                    const float4 *tp = g.tri + TRI_STRIDE * (size_t)tri;
                     float4 a = tp[0], b = tp[1], c = tp[2];
                     hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
                     rank = __float_as_uint(c.w);
@@ -1339,7 +1339,7 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const float4 *work_in
         // regular (record_hit_is_regular): first lane of the group, then shared
         bool general = stepping && record == HIT_RETRY;
         if (stepping && record >= 0) {
-            const float4 *t = g.tri + 3 * (size_t)record;
+            const float4 *t = g.tri + TRI_STRIDE * (size_t)record;
             general = !record_hit_is_regular(g, t[0], t[1], t[2], p.position, p.direction, distance);
         }
         if (__any(general)) {
@@ -1427,7 +1427,7 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
 #endif
 __global__ __launch_bounds__(PHYS_BLOCK) __attribute__((amdgpu_waves_per_eu(PHYS_WAVES_PER_EU))) void
 k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32_t *output_queue, float4 *work_out,
-          const float4 *rays, const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base,
+          const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base,
           int use_weights, int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters)
 {
     // Two passes per step.  Main pass (fixup = 0): every slot of the working set; a slot the ray cast
@@ -1451,29 +1451,29 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
         const int slot = fixup ? (int)retry_list[id] : id;
         int tri = hit_triangle[slot];
         const float hit_dist = hit_distance[slot];
-        if (!fixup && tri >= 0) {
-            // is the fast walk's winner one the reference is sure to find too?  (origin and direction as
-            // the ray cast saw them: the ray record)
-            const float4 *r = rays + 4 * (size_t)slot;
-            const float4 r0 = r[0], r1 = r[1];
-            const float4 *t = g.tri + 3 * (size_t)tri;
-            if (!record_hit_is_regular(g, t[0], t[1], t[2], mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), hit_dist)) {
-                retry_list[atomicAdd(&st->retry, 1u)] = (uint32_t)slot;
-                tri = HIT_RETRY;
-            }
-        }
+        float4 w0, w1, w2, w3;
         if (tri != HIT_RETRY) {
-            if (tri != HIT_NAN) nsteps++;
             const float4 *w = work_in + 4 * (size_t)slot;
-            const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3];
             photon_id = __float_as_uint(w3.w);
             p.position = mk3(w0.x, w0.y, w0.z);
             p.direction = mk3(w1.x, w1.y, w1.z);
             p.polarization = mk3(w2.x, w2.y, w2.z);
             if (renorm) {
-                p.direction = p.direction / norm(p.direction);
+                p.direction = p.direction / norm(p.direction);           // (the same arithmetic as k_ray_setup: the ray's)
                 p.polarization = p.polarization / norm(p.polarization);
             }
+            if (!fixup && tri >= 0) {
+                // is the fast walk's winner one the reference is sure to find too?
+                const float4 *t = g.tri + TRI_STRIDE * (size_t)tri;
+                if (!record_hit_is_regular(g, t[0], t[1], t[2], p.position, p.direction, hit_dist)) {
+                    retry_list[atomicAdd(&st->retry, 1u)] = (uint32_t)slot;
+                    tri = HIT_RETRY;
+                }
+            }
+        }
+        if (tri != HIT_RETRY) {
+            if (tri != HIT_NAN) nsteps++;
             p.wavelength = w0.w;
             p.time = w1.w;
             p.weight = w2.w;
@@ -1969,7 +1969,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     unsigned pblocks = (unsigned)std::min<long long>((n_upper + PHYS_BLOCK - 1) / PHYS_BLOCK, (long long)ctx->physics_blocks);
     DeviceCounters *pc = ctx->counting ? ctx->d_counters : nullptr;
     hipLaunchKernelGGL(k_physics, dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
-                       ctx->rays, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
+                       ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
                        ctx->retry_list, 0, pc);
     if (ctx->counting)
         hipLaunchKernelGGL((k_raycast_retry<true>), dim3(256), block, 0, ctx->stream, geom->view, ctx->rays, st,
@@ -1978,7 +1978,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
         hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, ctx->rays, st,
                            ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
     hipLaunchKernelGGL(k_physics, dim3(std::min(pblocks, 64u)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
-                       work_out, ctx->rays, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
+                       work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
                        scatter_first, ctx->retry_list, 1, pc);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(hipGetLastError());
@@ -2103,7 +2103,7 @@ __global__ void k_distance_finish(GeoView g, int n, const float4 *rays, const in
     if (rec >= 0) {
         const float4 *r = rays + 4 * (size_t)slot;
         const float4 r0 = r[0], r1 = r[1];
-        const float4 *t = g.tri + 3 * (size_t)rec;
+        const float4 *t = g.tri + TRI_STRIDE * (size_t)rec;
         const float4 a = t[0], b = t[1], c = t[2];
         const float dist = hit_distance[slot];
         if (!record_hit_is_regular(g, a, b, c, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), dist)) {
@@ -2446,19 +2446,19 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     // 48-byte triangle records in device order, staged in chunks
     {
         void *dtri = nullptr;
-        size_t bytes = nrecords * 48;
+        size_t bytes = nrecords * (16 * TRI_STRIDE);
         hipError_t e = hipMalloc(&dtri, bytes);
         if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "hipMalloc(%zu) for triangle records: %s", bytes, hipGetErrorString(e)); }
         g->allocations.push_back(dtri);
         g->device_bytes += bytes;
         const size_t CH = 1u << 22;
-        std::vector<float> stage(std::min(nrecords, CH) * 12);
+        std::vector<float> stage(std::min(nrecords, CH) * (4 * TRI_STRIDE), 0.0f);
         for (size_t t0 = 0; t0 < nrecords; t0 += CH) {
             size_t t1 = std::min(nrecords, t0 + CH);
             chroma_host::parallel_for(t1 - t0, [&](size_t lo, size_t hi) {
                 for (size_t k = t0 + lo; k < t0 + hi; k++) {
                     size_t t = dev_to_tri[k];
-                    float *r = stage.data() + (k - t0) * 12;
+                    float *r = stage.data() + (k - t0) * (4 * TRI_STRIDE);
                     for (int c = 0; c < 3; c++) {
                         const float *vv = d->vertices + 3 * (size_t)d->triangles[3 * t + c];
                         r[4 * c] = vv[0]; r[4 * c + 1] = vv[1]; r[4 * c + 2] = vv[2];
@@ -2467,7 +2467,7 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
                     memcpy(&r[3], &code, 4); memcpy(&r[7], &tid, 4); memcpy(&r[11], &rank, 4);
                 }
             });
-            e = hipMemcpy((char *)dtri + t0 * 48, stage.data(), (t1 - t0) * 48, hipMemcpyHostToDevice);
+            e = hipMemcpy((char *)dtri + t0 * (16 * TRI_STRIDE), stage.data(), (t1 - t0) * (16 * TRI_STRIDE), hipMemcpyHostToDevice);
             if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "triangle upload: %s", hipGetErrorString(e)); }
         }
         v.tri = (const float4 *)dtri;
@@ -2557,7 +2557,7 @@ int chroma_geometry_device_ptr(chroma_geometry *g, const char *name, void **d_pt
     else if (n == "colors") { p = g->d_colors; bytes = g->ntriangles * 4; }
     else if (n == "solid_id_map") { p = (void *)g->view.solid_id_map; bytes = g->ntriangles * 4; }
     else if (n == "solid_id_to_channel_index") { p = (void *)g->view.solid_id_to_channel_index; bytes = (size_t)g->view.nsolids * 4; }
-    else if (n == "triangle_records") { p = (void *)g->view.tri; bytes = g->nrecords * 48; }
+    else if (n == "triangle_records") { p = (void *)g->view.tri; bytes = g->nrecords * (16 * TRI_STRIDE); }
     else if (n == "wide_nodes") { p = (void *)g->view.wnodes; bytes = g->nwide * 128; }
     else if (n == "tri_to_dev") { p = (void *)g->view.tri_to_dev; bytes = g->ntriangles * 4; }
     else if (n == "dev_to_tri") { p = (void *)g->view.dev_to_tri; bytes = g->nrecords * 4; }

@@ -52,6 +52,11 @@ __device__ inline void store3(float *p, size_t i, v3 v) { p[3 * i] = v.x; p[3 * 
 //   tables  float[...]               optics tables, row-major [row][wavelength_n]
 struct SurfaceInfo { uint32_t model; uint32_t transmissive; float thickness; int32_t dichroic_index; };
 
+// float4s per triangle record: {v0, material code} {v1, triangle id} {v2, rank}.  4 pads a record to
+// 64 bytes, so that none straddles two 128-byte lines (a quarter of the 48-byte ones do).
+#ifndef TRI_STRIDE
+#define TRI_STRIDE 3
+#endif
 struct GeoView {
     const uint4  *nodes;             // traversal copy: leaf child = device triangle index
     const uint4  *wnodes;            // derived 8-wide tree, 8 entries (128 B) per node

@@ -319,7 +319,7 @@ __device__ inline int intersect_mesh_strict(const GeoView &g, v3 origin, v3 dire
                 if ((nd.w >> CHROMA_CHILD_BITS) == 0) {
                     if ((int)child == last_hit_record) continue;
                     if (COUNT) cnt.tris++;
-                    const float4 *t = g.tri + 3 * (size_t)child;
+                    const float4 *t = g.tri + TRI_STRIDE * (size_t)child;
                     float4 a = t[0], b = t[1], c = t[2];
                     float distance;
                     if (intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance)) {
@@ -455,7 +455,7 @@ __device__ inline void apply_hit(State &s, Photon &p, const GeoView &g, int tria
         return;
     }
     size_t record = g.tri_to_dev[triangle];
-    const float4 *t = g.tri + 3 * record;
+    const float4 *t = g.tri + TRI_STRIDE * record;
     apply_hit_record(s, p, g, record, distance, t[0], t[1], t[2]);
 }
 // by record index (what the per-step ray cast hands over); the record names its triangle
@@ -467,7 +467,7 @@ __device__ inline void apply_hit_dev(State &s, Photon &p, const GeoView &g, int 
         p.history |= CHROMA_NO_HIT;
         return;
     }
-    const float4 *t = g.tri + 3 * (size_t)record;
+    const float4 *t = g.tri + TRI_STRIDE * (size_t)record;
     float4 a = t[0], b = t[1], c = t[2];
     p.last_hit_triangle = (int)__float_as_uint(b.w);
     apply_hit_record(s, p, g, (size_t)record, distance, a, b, c);
