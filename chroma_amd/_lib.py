@@ -137,6 +137,7 @@ SIGNATURES = {
     'chroma_propagate_stats_read': (c_int32, [c_void_p, POINTER(PropagateStats)]),
     'chroma_set_counting': (c_int32, [c_void_p, c_int32]),
     'chroma_set_walk': (c_int32, [c_void_p, c_int32]),
+    'chroma_set_tail': (c_int32, [c_void_p, c_int32]),
 }
 
 _lib = None

@@ -81,7 +81,7 @@ struct chroma_ctx {
     uint2 *coop_spill = nullptr;           // [coop_waves][8][COOP_SPILL]
     int ray_chunk = 256, coop_chunk = 64;  // rays a persistent wave takes from the queue per atomic (big batches)
     int fused_tail = 1;                    // 0 (CHROMA_TAIL=split): the last photons also take one launch set per step
-    int split_tail = 1;                    // 0 (CHROMA_TAIL=fused): the last launch of chroma_propagate is the fused kernel
+    int split_tail = 1;                    // 0 (CHROMA_TAIL=fused): chroma_propagate launches the fused kernel only, as the reference does
     int wide_walk = CHROMA_WALK_QUAD;      // CHROMA_WALK_*: reference tree | wide tree with 1, 8 or 4 (default) lanes per ray
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
 };
@@ -2799,6 +2799,16 @@ int chroma_set_walk(chroma_ctx *ctx, int32_t mode)
     if (mode != CHROMA_WALK_REFERENCE && mode != CHROMA_WALK_WIDE && mode != CHROMA_WALK_COOP && mode != CHROMA_WALK_QUAD)
         return set_error(CHROMA_ERR_INVALID, "unknown walk mode %d", mode);
     ctx->wide_walk = mode;
+    return CHROMA_OK;
+}
+
+int chroma_set_tail(chroma_ctx *ctx, int32_t mode)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    if (mode != CHROMA_TAIL_COOP && mode != CHROMA_TAIL_SPLIT && mode != CHROMA_TAIL_FUSED)
+        return set_error(CHROMA_ERR_INVALID, "unknown tail mode %d", mode);
+    ctx->split_tail = mode != CHROMA_TAIL_FUSED;
+    ctx->fused_tail = mode == CHROMA_TAIL_COOP;
     return CHROMA_OK;
 }
 

@@ -89,6 +89,10 @@ class Context(object):
         """'quad' (default), 'coop', 'wide' or 'reference': how the per-step ray cast walks (same results)."""
         _lib.check(self._lib.chroma_set_walk(self.handle, {'reference': 0, 'wide': 1, 'coop': 2, 'quad': 3}[mode]))
 
+    def set_tail(self, mode):
+        """'coop' (default), 'split' or 'fused': how propagate() finishes -- or, with 'fused', runs -- a batch."""
+        _lib.check(self._lib.chroma_set_tail(self.handle, {'coop': 0, 'split': 1, 'fused': 2}[mode]))
+
     def read_stats(self):
         stats = _lib.PropagateStats()
         _lib.check(self._lib.chroma_propagate_stats_read(self.handle, ctypes.byref(stats)))

@@ -336,6 +336,17 @@ int chroma_set_counting(chroma_ctx *ctx, int32_t enabled);
 #define CHROMA_WALK_QUAD      3   /* the wide tree with four lanes per ray, two child entries per lane */
 int chroma_set_walk(chroma_ctx *ctx, int32_t mode);
 
+/* How chroma_propagate finishes a batch and, with FUSED, how it runs it at all (same results; for
+ * tests and benchmarks).  COOP: per-step launch sets, then ONE cooperative launch for all remaining
+ * steps once fewer than 8192 photons are alive.  SPLIT: per-step launch sets to the end.  FUSED: the
+ * reference's own shape (chroma/gpu/photon.py:225-252) -- the lane-per-photon kernel of
+ * chroma_propagate_step, one step per launch, then all remaining steps in one.
+ * Env CHROMA_TAIL=coop|split|fused sets the initial mode of a context. */
+#define CHROMA_TAIL_COOP  0
+#define CHROMA_TAIL_SPLIT 1
+#define CHROMA_TAIL_FUSED 2
+int chroma_set_tail(chroma_ctx *ctx, int32_t mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -457,9 +457,8 @@ def test_exact_ties_follow_the_reference_test_order(gpu, oracle_mod, tiny_geomet
         assert_bit_exact(gp2.get(), want, 'aimed rays, %s walk' % mode)
 
 
-def test_edge_inputs_in_a_large_batch(gpu, oracle_mod, tiny_geometry):
-    """Terminal, NaN, exactly axis-parallel, outside-the-world and repeated-last-hit photons inside a
-    batch large enough for per-step launches (>= 8192 alive): same as the oracle, bit for bit."""
+def _edge_photons():
+    """Terminal, NaN, exactly axis-parallel, outside-the-world and repeated-last-hit photons in a batch of 24000."""
     ph = bomb(24000, 17)
     n = len(ph)
     ph.flags[100:200] = event.BULK_ABSORB                      # terminal: untouched
@@ -474,6 +473,14 @@ def test_edge_inputs_in_a_large_batch(gpu, oracle_mod, tiny_geometry):
     ph.dir[1000:1050] = [1.0, 0, 0]                            # ... pointing away
     ph.dir[1050:1100] = [-1.0, -1.0, -1.0]                     # ... pointing at it
     ph.last_hit_triangles[2000:2200] = np.arange(200)          # a last hit that is not on the ray: no effect
+    return ph
+
+
+def test_edge_inputs_in_a_large_batch(gpu, oracle_mod, tiny_geometry):
+    """Terminal, NaN, exactly axis-parallel, outside-the-world and repeated-last-hit photons inside a
+    batch large enough for per-step launches (>= 8192 alive): same as the oracle, bit for bit."""
+    ph = _edge_photons()
+    n = len(ph)
     gg, gp, got, want, counters, stats, ostats = run_both(gpu, oracle_mod, tiny_geometry, ph, max_steps=20)
     assert_bit_exact(got, want, 'edge inputs, large batch')
     assert np.array_equal(gp.rng_counters.get(), counters)
@@ -481,6 +488,24 @@ def test_edge_inputs_in_a_large_batch(gpu, oracle_mod, tiny_geometry):
     assert got.flags[300] == (event.NO_HIT | event.NAN_ABORT) and got.flags[301] == (event.NO_HIT | event.NAN_ABORT)
     assert (got.flags[1000:1050] == event.NO_HIT).all()
     assert stats['launches'] == ostats['launches'] and stats['photon_steps'] == ostats['photon_steps']
+
+
+@pytest.mark.parametrize('tail', ['split', 'fused'])
+def test_tail_modes_give_the_same_photons(gpu, oracle_mod, tiny_geometry, tail):
+    """chroma_set_tail: per-step launch sets to the end, and the reference's own launch shape (the
+    lane-per-photon kernel for every launch), against the oracle on the edge-input batch -- run to the
+    end, and cut off after 3 steps with photons still alive (they go back to the caller's arrays)."""
+    ph = _edge_photons()
+    gpu.get_context().set_tail(tail)
+    try:
+        for max_steps in (20, 3):
+            gg, gp, got, want, counters, stats, ostats = run_both(gpu, oracle_mod, tiny_geometry, ph, max_steps=max_steps)
+            assert_bit_exact(got, want, 'edge inputs, %s tail, max_steps %d' % (tail, max_steps))
+            assert np.array_equal(gp.rng_counters.get(), counters)
+            assert stats['launches'] == ostats['launches'] and stats['photon_steps'] == ostats['photon_steps']
+        assert ((got.flags & event.TERMINAL_MASK) == 0).sum() > 100
+    finally:
+        gpu.get_context().set_tail('coop')
 
 
 def test_large_batch_properties(gpu, oracle_mod, tiny_geometry):
