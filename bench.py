@@ -57,6 +57,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1 and 'CHROMA_HOST_THREADS' not in os.environ:
+        # every rank builds the same geometry on the same host at the same time: share the cores
+        os.environ['CHROMA_HOST_THREADS'] = str(max(4, (os.cpu_count() or 8) // int(os.environ.get('LOCAL_WORLD_SIZE', world))))
 
     # torch first: it carries its own libamdhip64 under the same SONAME, so loading it before
     # libchroma_hip.so makes both share one HIP runtime in this process.

@@ -2,16 +2,21 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <thread>
 #include <vector>
 
 namespace chroma_host {
 
+// threads of the host-side builders: the machine's, at most 64, or CHROMA_HOST_THREADS (several
+// processes building the same geometry on one node, one per GPU, share the cores)
 inline unsigned hw_threads()
 {
     unsigned n = std::thread::hardware_concurrency();
-    return std::max(1u, std::min(n ? n : 1u, 64u));
+    n = std::max(1u, std::min(n ? n : 1u, 64u));
+    if (const char *e = getenv("CHROMA_HOST_THREADS")) { int v = atoi(e); if (v > 0) n = std::min<unsigned>((unsigned)v, 64u); }
+    return n;
 }
 
 template <class F>
