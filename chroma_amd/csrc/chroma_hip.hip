@@ -897,6 +897,9 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #ifndef QUAD_WAVES_PER_EU
 #define QUAD_WAVES_PER_EU 7
 #endif
+#ifndef QUAD_UNIFORM_SPILL
+#define QUAD_UNIFORM_SPILL 1   // the spill paths of push and pop behind one wave-uniform test each
+#endif
 #ifndef QUAD_FLUSH
 #define QUAD_FLUSH 8         // run the triangle tests once a ray has this many postponed (a visit adds up to 8)
 #endif
@@ -1029,6 +1032,19 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
         more = !exhausted || loc_next < loc_end;
         const int stop_at = more ? max(0, __popcll(__ballot(active && j == 0)) - QUAD_REFILL_MIN) : 0;
         do {
+#if QUAD_UNIFORM_SPILL
+            if (!__any(sp > COOP_STACK)) {
+                if (active && cur == WIDE_NONE) {
+                    while (sp > 0) {
+                        sp--;
+                        const uint32_t n = stack_n[sp];
+                        const float t = stack_t[sp];
+                        if (!(t > prune_t)) { cur = n; break; }
+                    }
+                    if (cur == WIDE_NONE) active = false;
+                }
+            } else
+#endif
             if (active && cur == WIDE_NONE) {
                 while (sp > 0) {
                     sp--;
@@ -1075,19 +1091,28 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     const bool qa = ia && !na, qb = ib && !nb;
                     const uint32_t mo = mi & ~(1u << ((ne >> 1) | ((ne & 1u) << 2)));
                     int pos = sp + __popc(mo & below2);
-                    if (qa) {
-                        if (pos < COOP_STACK) { stack_n[pos] = ea.w; stack_t[pos] = ta; }
-                        else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(ea.w, __float_as_uint(ta));
-                        pos++;
-                    }
-                    if (qb) {
-                        if (pos < COOP_STACK) { stack_n[pos] = eb.w; stack_t[pos] = tb; }
-                        else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(eb.w, __float_as_uint(tb));
-                    }
                     sp += __popc(mo);
-                    if (sp > COOP_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
-                        triangle_index = HIT_RETRY;
-                        active = false; npend = 0; cur = WIDE_NONE; sp = 0;
+#if QUAD_UNIFORM_SPILL
+                    if (!__any(sp > COOP_STACK)) {
+                        // every ray of the wave stays inside its LDS stack (almost always): two plain stores
+                        if (qa) { stack_n[pos] = ea.w; stack_t[pos] = ta; pos++; }
+                        if (qb) { stack_n[pos] = eb.w; stack_t[pos] = tb; }
+                    } else
+#endif
+                    {
+                        if (qa) {
+                            if (pos < COOP_STACK) { stack_n[pos] = ea.w; stack_t[pos] = ta; }
+                            else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(ea.w, __float_as_uint(ta));
+                            pos++;
+                        }
+                        if (qb) {
+                            if (pos < COOP_STACK) { stack_n[pos] = eb.w; stack_t[pos] = tb; }
+                            else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(eb.w, __float_as_uint(tb));
+                        }
+                        if (sp > COOP_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
+                            triangle_index = HIT_RETRY;
+                            active = false; npend = 0; cur = WIDE_NONE; sp = 0;
+                        }
                     }
                 }
             }
