@@ -362,6 +362,21 @@ def test_chroma_sim_driver(gpu, tmp_path):
         ch = f['ev%d/channel' % i]
         assert len(ch) > 50 and ch.max() < 53 and len(f['ev%d/t' % i]) == len(ch)
         assert f['ev%d/daq_hit' % i].sum() == len(np.unique(ch))       # every hit channel fired (weight 1)
+    # the photons themselves (bin/chroma-sim:51-56) and their step-by-step tracks
+    out2 = tmp_path / 'photons.npz'
+    assert main(['@chroma_amd.demo.tiny', '-n', '2', '--nphotons', '1500', '-s', '7', '--max-steps', '6',
+                 '--save-photons-beg', '--save-photons-end', '--track', '-o', str(out2)]) == 0
+    f = np.load(out2)
+    for i in range(2):
+        beg, end = f['ev%d/photons_beg/pos' % i], f['ev%d/photons_end/pos' % i]
+        assert beg.shape == (1500, 3) and end.shape == (1500, 3) and (beg == 0).all() and (end != 0).any()
+        who, tpos, tt = f['ev%d/track/photon' % i], f['ev%d/track/pos' % i], f['ev%d/track/t' % i]
+        assert len(who) == len(tpos) == len(tt) and set(np.unique(who)) == set(range(1500))
+        first = np.r_[True, who[1:] != who[:-1]]
+        assert (tpos[first] == 0).all()                                 # a track starts where the photon did
+        last = np.r_[who[1:] != who[:-1], True]
+        assert np.array_equal(tpos[last], end[who[last]])               # ... and ends where it ended
+        assert (np.diff(tt)[~first[1:]] >= 0).all()                     # time runs forward along a track
 
 
 def test_c_abi_rejects_bad_input(gpu, tiny_geometry):
