@@ -121,6 +121,8 @@ SIGNATURES = {
     'chroma_daq_reset': (c_int32, [c_void_p, c_float, c_uint32, c_void_p, c_void_p, c_void_p]),
     'chroma_daq_acquire': (c_int32, [c_void_p, c_void_p, POINTER(DaqTables), c_int32, c_int32, c_uint32, POINTER(PhotonArrays),
                                      Rng, c_uint32, c_float, c_void_p, c_void_p, c_void_p]),
+    'chroma_daq_acquire_many': (c_int32, [c_void_p, c_void_p, POINTER(DaqTables), c_int32, c_int32, c_uint32, POINTER(PhotonArrays),
+                                          Rng, c_uint32, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     'chroma_daq_convert': (c_int32, [c_void_p, c_uint32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'chroma_generate_bomb': (c_int32, [c_void_p, POINTER(PhotonArrays), c_uint64, c_uint64, c_uint64,
                                        POINTER(c_float), c_float, c_float]),

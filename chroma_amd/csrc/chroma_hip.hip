@@ -1825,6 +1825,41 @@ __global__ void k_run_daq(GeoView g, chroma_daq_tables tab, int first_photon, in
     }
 }
 
+// run_daq_many (daq.cu:88-150): ndaq independent acquisitions of the same photons side by side, copy i
+// in channels [i * stride, (i + 1) * stride); a copy adds a unit normal jitter to the hit time.  The
+// reference gives a photon a block and its copies the block's threads; here a thread is one (photon,
+// copy) pair and copy i draws from words 8 i ... of the photon's DAQ stream, so copies are independent
+// and the result does not depend on the launch shape.
+__global__ void k_run_daq_many(GeoView g, chroma_daq_tables tab, int first_photon, int nphotons, uint32_t detection_state,
+                               const float *photon_times, const uint32_t *photon_histories, const int32_t *last_hit_triangles,
+                               const float *weights, uint64_t seed, uint64_t id_base, uint32_t acquisition, float global_weight,
+                               int ndaq, int channel_stride,
+                               uint32_t *earliest_time_int, uint32_t *channel_q_int, uint32_t *channel_histories)
+{
+    long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long)nphotons * ndaq) return;
+    int photon_id = (int)(id / ndaq) + first_photon, copy = (int)(id % ndaq);
+    int triangle_id = last_hit_triangles[photon_id];
+    if (triangle_id <= -1) return;
+    uint32_t history = photon_histories[photon_id];
+    int channel_index = g.solid_id_to_channel_index[g.solid_id_map[triangle_id]];
+    if (channel_index < 0 || !(history & detection_state)) return;
+    cm_rng rng;
+    cm_rng_init(&rng, seed, id_base + (uint64_t)photon_id, 8u * (uint32_t)copy);
+    rng.stream = 1u + acquisition;
+    float weight = weights[photon_id] * global_weight;
+    int channel_offset = channel_index + copy * channel_stride;
+    if (cm_rng_uniform(&rng) < weight) {
+        float jitter = cm_rng_normal(&rng);
+        float time = photon_times[photon_id] + jitter +
+                     interp_table(cm_rng_uniform(&rng), tab.time_cdf_len, tab.d_time_cdf_y, tab.d_time_cdf_x);
+        float charge = interp_table(cm_rng_uniform(&rng), tab.charge_cdf_len, tab.d_charge_cdf_y, tab.d_charge_cdf_x);
+        uint32_t charge_int = (uint32_t)cm_roundf(charge / tab.charge_unit);
+        atomicMin(earliest_time_int + channel_offset, __float_as_uint(time));
+        atomicAdd(channel_q_int + channel_offset, charge_int);
+        atomicOr(channel_histories + channel_offset, history);
+    }
+}
 __global__ void k_daq_convert(uint32_t n, float charge_unit, const uint32_t *time_ints, const uint32_t *q_ints, float *t_out, float *q_out)
 {
     uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3043,6 +3078,30 @@ int chroma_daq_acquire(chroma_ctx *ctx, chroma_geometry *geom, const chroma_daq_
                        nphotons, detection_state, photons->t, photons->flags, photons->last_hit_triangles, photons->weights,
                        rng.seed, rng.photon_id_base, acquisition, global_weight, d_earliest_time_int, d_channel_q_int,
                        d_channel_histories);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+int chroma_daq_acquire_many(chroma_ctx *ctx, chroma_geometry *geom, const chroma_daq_tables *tables, int32_t first_photon,
+                            int32_t nphotons, uint32_t detection_state, const chroma_photon_arrays *photons, chroma_rng rng,
+                            uint32_t acquisition, float global_weight, int32_t ndaq, int32_t channel_stride,
+                            uint32_t *d_earliest_time_int, uint32_t *d_channel_q_int, uint32_t *d_channel_histories)
+{
+    if (!ctx || !geom || !tables || !d_earliest_time_int || !d_channel_q_int || !d_channel_histories)
+        return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (!geom->view.nsolids) return set_error(CHROMA_ERR_INVALID, "geometry has no detector channel map");
+    if (ndaq < 1 || channel_stride < (int32_t)geom->view.nchannels)
+        return set_error(CHROMA_ERR_INVALID, "ndaq must be positive and the channel stride at least the number of channels");
+    if (tables->time_cdf_len < 2 || tables->charge_cdf_len < 2 || !tables->d_time_cdf_x || !tables->d_time_cdf_y ||
+        !tables->d_charge_cdf_x || !tables->d_charge_cdf_y || !(tables->charge_unit > 0.0f))
+        return set_error(CHROMA_ERR_INVALID, "DAQ tables: need two CDFs of at least 2 points and a positive charge unit");
+    int rc = check_photons(photons, false); if (rc) return rc;
+    if (nphotons <= 0) return CHROMA_OK;
+    const long long total = (long long)nphotons * ndaq;
+    hipLaunchKernelGGL(k_run_daq_many, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, geom->view, *tables,
+                       first_photon, nphotons, detection_state, photons->t, photons->flags, photons->last_hit_triangles,
+                       photons->weights, rng.seed, rng.photon_id_base, acquisition, global_weight, ndaq, channel_stride,
+                       d_earliest_time_int, d_channel_q_int, d_channel_histories);
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
 }

@@ -1,11 +1,12 @@
 """GPUDaq / GPUChannels: per-channel earliest hit time, charge and history
 (reference: chroma/gpu/daq.py:8-100 over chroma/cuda/daq.cu).
 
-ndaq == 1 only (``run_daq``); the replicated-DAQ kernel ``run_daq_many`` serves the
-likelihood code, which is outside this engine's scope.  The three random numbers a
-detected photon consumes (weight gate, time smear, charge) come from Philox stream
-``1 + acquisition`` of that photon, so propagation draws are not disturbed and two
-acquisitions of the same photons differ.
+``ndaq == 1`` runs ``run_daq``; ``ndaq > 1`` runs ``run_daq_many`` (daq.cu:88-150): that many
+independent acquisitions of the same photons side by side, each with a unit normal jitter on the hit
+time (``GPUChannels.iterate_copies`` walks them).  The random numbers a detected photon consumes
+(weight gate, jitter, time smear, charge) come from Philox stream ``1 + acquisition`` of that photon
+(copy i from word 8 i on), so propagation draws are not disturbed and two acquisitions of the same
+photons differ.
 """
 import ctypes
 
@@ -53,8 +54,8 @@ def _padded_cdf(cdf_x, cdf_y):
 
 class GPUDaq(object):
     def __init__(self, gpu_detector, ndaq=1):
-        if ndaq != 1:
-            raise NotImplementedError('ndaq > 1 (run_daq_many) is not part of this engine')
+        if ndaq < 1:
+            raise ValueError('ndaq must be at least 1')
         self.ctx = gpu_detector.ctx
         self.gpu_detector = gpu_detector
         n = gpu_detector.nchannels * ndaq
@@ -89,11 +90,19 @@ class GPUDaq(object):
             nphotons = len(gpuphotons.pos) - start_photon
         rng = gpuphotons._rng(rng_states)
         s = _structure(gpuphotons)
-        _lib.check(self.ctx._lib.chroma_daq_acquire(self.ctx.handle, self.gpu_detector.handle, ctypes.byref(self.tables),
-                                                    int(start_photon), int(nphotons), event.SURFACE_DETECT,
-                                                    ctypes.byref(s), rng, self.acquisition, float(weight),
-                                                    self.earliest_time_int_gpu.ptr, self.channel_q_int_gpu.ptr,
-                                                    self.channel_history_gpu.ptr))
+        if self.ndaq == 1:
+            _lib.check(self.ctx._lib.chroma_daq_acquire(self.ctx.handle, self.gpu_detector.handle, ctypes.byref(self.tables),
+                                                        int(start_photon), int(nphotons), event.SURFACE_DETECT,
+                                                        ctypes.byref(s), rng, self.acquisition, float(weight),
+                                                        self.earliest_time_int_gpu.ptr, self.channel_q_int_gpu.ptr,
+                                                        self.channel_history_gpu.ptr))
+        else:
+            _lib.check(self.ctx._lib.chroma_daq_acquire_many(self.ctx.handle, self.gpu_detector.handle, ctypes.byref(self.tables),
+                                                             int(start_photon), int(nphotons), event.SURFACE_DETECT,
+                                                             ctypes.byref(s), rng, self.acquisition, float(weight),
+                                                             int(self.ndaq), int(self.stride),
+                                                             self.earliest_time_int_gpu.ptr, self.channel_q_int_gpu.ptr,
+                                                             self.channel_history_gpu.ptr))
         self.acquisition += 1
         self.ctx.synchronize()
 

@@ -271,6 +271,17 @@ int chroma_daq_acquire(chroma_ctx *ctx, chroma_geometry *geom, const chroma_daq_
                        const chroma_photon_arrays *photons, chroma_rng rng, uint32_t acquisition,
                        float global_weight, uint32_t *d_earliest_time_int, uint32_t *d_channel_q_int,
                        uint32_t *d_channel_histories);
+/* `run_daq_many` (chroma/cuda/daq.cu:88-150; GPUDaq(ndaq > 1), chroma/gpu/daq.py:85-99): `ndaq`
+ * independent acquisitions of the same photons side by side -- copy i accumulates into channels
+ * [i * channel_stride, (i + 1) * channel_stride) of arrays of ndaq * channel_stride entries -- each
+ * adding a unit normal jitter to the hit time (the reference's curand_normal; here Box-Muller on the
+ * photon's stream, include/chroma_math.h).  Copy i of a photon draws from words 8 i ... of Philox
+ * stream 1 + acquisition of that photon. */
+int chroma_daq_acquire_many(chroma_ctx *ctx, chroma_geometry *geom, const chroma_daq_tables *tables,
+                            int32_t first_photon, int32_t nphotons, uint32_t detection_state,
+                            const chroma_photon_arrays *photons, chroma_rng rng, uint32_t acquisition,
+                            float global_weight, int32_t ndaq, int32_t channel_stride,
+                            uint32_t *d_earliest_time_int, uint32_t *d_channel_q_int, uint32_t *d_channel_histories);
 /* `convert_sortable_int_to_float` + `convert_charge_int_to_float` (daq.cu:152-173) */
 int chroma_daq_convert(chroma_ctx *ctx, uint32_t nchannels, float charge_unit, const uint32_t *d_earliest_time_int,
                        const uint32_t *d_channel_q_int, float *d_earliest_time, float *d_channel_q);

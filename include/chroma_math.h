@@ -365,4 +365,15 @@ CM_FN float cm_rng_uniform(cm_rng *r)
     return cm_u32_to_uniform(w);
 }
 
+/* A standard normal deviate by Box-Muller from two uniforms of the stream (the cosine branch only):
+ * stands in for curand_normal (call site: chroma/cuda/daq.cu:131). */
+CM_FN float cm_rng_normal(cm_rng *r)
+{
+    float u1 = cm_rng_uniform(r);               /* (0, 1]: the logarithm is finite */
+    float u2 = cm_rng_uniform(r);
+    float s, c;
+    cm_sincosf(6.2831855f * u2, &s, &c);
+    return cm_sqrtf(-2.0f * cm_logf(u1)) * c;
+}
+
 #endif /* CHROMA_MATH_H */

@@ -53,6 +53,10 @@ def load(variant='contract'):
     lib.oracle_run_daq.restype = c_int32
     lib.oracle_run_daq.argtypes = [POINTER(_abi.GeometryDesc), POINTER(_abi.DaqTables), c_int32, c_int32, c_uint32,
                                    POINTER(_abi.PhotonArrays), _abi.Rng, c_uint32, c_float, c_void_p, c_void_p, c_void_p]
+    lib.oracle_run_daq_many.restype = c_int32
+    lib.oracle_run_daq_many.argtypes = [POINTER(_abi.GeometryDesc), POINTER(_abi.DaqTables), c_int32, c_int32, c_uint32,
+                                        POINTER(_abi.PhotonArrays), _abi.Rng, c_uint32, c_float, c_int32, c_int32,
+                                        c_void_p, c_void_p, c_void_p]
     lib.oracle_math.restype = c_int32
     lib.oracle_math.argtypes = [c_int32, c_uint64, c_void_p, c_void_p, c_void_p]
     lib.oracle_philox.restype = None
@@ -162,6 +166,27 @@ def run_daq(packed, photons, tables_host, charge_unit, seed, photon_id_base=0, a
     lib.oracle_run_daq(ctypes.byref(packed.desc), ctypes.byref(tab), int(start_photon), int(nphotons), event.SURFACE_DETECT,
                        ctypes.byref(hp.struct), _abi.Rng(int(seed), int(photon_id_base)), int(acquisition), float(weight),
                        t_int.ctypes.data, q_int.ctypes.data, hist.ctypes.data)
+    t = t_int.view(np.float32)
+    return t, (q_int.astype(np.float32) * np.float32(charge_unit)).astype(np.float32), hist, t < 1e8
+
+
+def run_daq_many(packed, photons, tables_host, charge_unit, seed, ndaq, photon_id_base=0, acquisition=0, weight=1.0,
+                 start_photon=0, nphotons=None, variant='contract'):
+    """run_daq_many on HOST arrays: ``ndaq`` acquisitions side by side (copy i = entries [i*nch, (i+1)*nch)).
+    Returns (earliest_time float32, charge float32, histories uint32, hit mask), each of ndaq * nchannels entries."""
+    lib = load(variant)
+    hp = HostPhotons(photons)
+    tx, ty, qx, qy = [np.ascontiguousarray(a, dtype=np.float32) for a in tables_host]
+    tab = _abi.DaqTables(tx.ctypes.data, ty.ctypes.data, len(tx), qx.ctypes.data, qy.ctypes.data, len(qx), float(charge_unit))
+    nch = packed.desc.nchannels
+    t_int = np.full(nch * ndaq, np.float32(1e9).view(np.uint32), dtype=np.uint32)
+    q_int = np.zeros(nch * ndaq, dtype=np.uint32)
+    hist = np.zeros(nch * ndaq, dtype=np.uint32)
+    if nphotons is None:
+        nphotons = hp.n - start_photon
+    lib.oracle_run_daq_many(ctypes.byref(packed.desc), ctypes.byref(tab), int(start_photon), int(nphotons), event.SURFACE_DETECT,
+                            ctypes.byref(hp.struct), _abi.Rng(int(seed), int(photon_id_base)), int(acquisition), float(weight),
+                            int(ndaq), int(nch), t_int.ctypes.data, q_int.ctypes.data, hist.ctypes.data)
     t = t_int.view(np.float32)
     return t, (q_int.astype(np.float32) * np.float32(charge_unit)).astype(np.float32), hist, t < 1e8
 

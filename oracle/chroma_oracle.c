@@ -1119,6 +1119,42 @@ int oracle_run_daq(const chroma_geometry_desc *g, const chroma_daq_tables *tab, 
     return 0;
 }
 
+/* run_daq_many (chroma/cuda/daq.cu:88-150): ndaq acquisitions side by side, copy i in channels
+ * [i * stride, (i + 1) * stride), each with a unit normal jitter on the hit time.  Copy i of a photon
+ * draws from words 8 i ... of the photon's DAQ stream (mirrors chroma_daq_acquire_many). */
+int oracle_run_daq_many(const chroma_geometry_desc *g, const chroma_daq_tables *tab, int32_t first_photon, int32_t nphotons,
+                        uint32_t detection_state, const chroma_photon_arrays *a, chroma_rng rng_desc, uint32_t acquisition,
+                        float global_weight, int32_t ndaq, int32_t channel_stride,
+                        uint32_t *earliest_time_int, uint32_t *channel_q_int, uint32_t *channel_histories)
+{
+    for (int id = 0; id < nphotons; id++) {
+        int photon_id = id + first_photon;
+        int triangle_id = a->last_hit_triangles[photon_id];
+        if (triangle_id <= -1) continue;
+        uint32_t history = a->flags[photon_id];
+        int channel_index = g->solid_id_to_channel_index[g->solid_id_map[triangle_id]];
+        if (channel_index < 0 || !(history & detection_state)) continue;
+        float weight = a->weights[photon_id] * global_weight;
+        for (int copy = 0; copy < ndaq; copy++) {
+            cm_rng rng;
+            cm_rng_init(&rng, rng_desc.seed, rng_desc.photon_id_base + (uint64_t)photon_id, 8u * (uint32_t)copy);
+            rng.stream = 1u + acquisition;
+            int channel_offset = channel_index + copy * channel_stride;
+            if (rng_u(&rng) < weight) {
+                float jitter = cm_rng_normal(&rng);
+                float time = a->t[photon_id] + jitter + interp_table(rng_u(&rng), tab->time_cdf_len, tab->d_time_cdf_y, tab->d_time_cdf_x);
+                float charge = interp_table(rng_u(&rng), tab->charge_cdf_len, tab->d_charge_cdf_y, tab->d_charge_cdf_x);
+                uint32_t charge_int = (uint32_t)cm_roundf(charge / tab->charge_unit);
+                uint32_t time_int = cm_f2u(time);
+                if (time_int < earliest_time_int[channel_offset]) earliest_time_int[channel_offset] = time_int;
+                channel_q_int[channel_offset] += charge_int;
+                channel_histories[channel_offset] |= history;
+            }
+        }
+    }
+    return 0;
+}
+
 /* Isotropic photon bomb, the benchmark source of chroma/benchmark.py:77-83 with the
  * formulas of chroma/sample.py:16-30 in single precision; photon i is drawn from the Philox
  * stream (seed, 0xB0B0000000000000 + id_base + i): dir = uniform_sphere (2 draws), an auxiliary

@@ -315,6 +315,18 @@ def test_daq_matches_oracle_and_reference_test(gpu, oracle_mod, tiny_geometry, t
         if acquisition == 0:
             first = ch.t.copy()
     assert not np.array_equal(first, ch.t)                 # a new acquisition draws new smearing
+    # ndaq > 1: run_daq_many, copies side by side (chroma/gpu/daq.py:85-99, daq.cu:88-150)
+    daq4 = gpu.GPUDaq(gg, ndaq=4)
+    daq4.begin_acquire()
+    daq4.acquire(gp, rng_states)
+    many = daq4.end_acquire()
+    t, q, hist, hit = oracle_mod.run_daq_many(tiny_packed, end, daq4._tables_host, daq4.charge_unit, seed=9, ndaq=4)
+    ch4 = many.get()
+    assert np.array_equal(ch4.hit, hit) and np.array_equal(ch4.t.view(np.uint32), t.view(np.uint32))
+    assert np.array_equal(ch4.q.view(np.uint32), q.view(np.uint32)) and np.array_equal(ch4.flags, hist)
+    copies = [c.get() for c in many.iterate_copies()]
+    assert len(copies) == 4 and all(len(c.t) == gg.nchannels for c in copies)
+    assert np.array_equal(copies[0].hit, copies[3].hit) and not np.array_equal(copies[0].t, copies[3].t)
 
     # test/test_detector.py: one photocathode box, single-photon events through Simulation(run_daq=True)
     from chroma_amd.sim import Simulation

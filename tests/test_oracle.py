@@ -172,6 +172,21 @@ def test_daq_oracle_time_and_charge_spread(oracle_mod):
     # nothing detected -> nothing hit; weight 0 -> nothing hit
     t, q, hist, hit = oracle_mod.run_daq(pk, end, tables, unit, seed=2, weight=0.0)
     assert not hit.any() and q.sum() == 0
+    # run_daq_many (daq.cu:88-150): copies of the acquisition side by side, each with a unit normal jitter
+    ndaq = 64
+    times = []
+    for i in detected[:60]:
+        t, q, hist, hit = oracle_mod.run_daq_many(pk, end, tables, unit, seed=2, ndaq=ndaq, start_photon=int(i), nphotons=1)
+        assert t.shape == (ndaq,) and hit.all() and (hist == end.flags[i]).all()
+        times.append(t)
+    times = np.concatenate(times)
+    # the jitter adds in quadrature to the 1.2 ns of the time CDF; the copies are independent draws
+    assert abs(np.std(times) - np.hypot(1.2, 1.0)) < 0.1 and abs(np.mean(times) - end.t[detected[0]]) < 0.5
+    assert len(np.unique(times)) > 0.99 * len(times)
+    t1, q1, _, _ = oracle_mod.run_daq_many(pk, end, tables, unit, seed=2, ndaq=1)
+    t4, q4, _, hit4 = oracle_mod.run_daq_many(pk, end, tables, unit, seed=2, ndaq=4)
+    assert np.array_equal(t4[:1], t1) and np.array_equal(q4[:1], q1)              # copy 0 does not depend on ndaq
+    assert hit4.all() and abs(q4.mean() / q1[0] - 1.0) < 0.05                     # every copy sees all the photons
 
 
 def test_numpy_restatement_agrees_with_the_c_oracle(oracle_mod, tiny_packed):
