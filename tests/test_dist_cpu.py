@@ -32,6 +32,12 @@ def _channel_arrays(geo, end, nchannels):
     return counts, earliest
 
 
+def _daq_tables():
+    x = np.linspace(0.0, 4.0, 9, dtype=np.float32)
+    y = np.linspace(0.0, 1.0, 9, dtype=np.float32)
+    return x, y, x + 1.0, y
+
+
 def _worker(rank, world, port, nphotons, outdir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -49,8 +55,13 @@ def _worker(rank, world, port, nphotons, outdir):
     end, _, _ = oracle.propagate(pk, photons, seed=12345, photon_id_base=lo, max_steps=100)
     counts, earliest = _channel_arrays(geo, end, geo.num_channels())
     counts, earliest = allreduce_channel_hits(counts, earliest)
+    # a DAQ acquisition over the shard (global photon ids again), reduced the same way
+    from chroma_amd.dist import allreduce_daq_channels
+    t, q, hist, _ = oracle.run_daq(pk, end, _daq_tables(), 1.0 / 64, seed=12345, photon_id_base=lo)
+    q_int = np.rint(q * 64).astype(np.uint32)
+    daq_t, daq_q, daq_h = allreduce_daq_channels(t.view(np.uint32), q_int, hist)
     if rank == 0:
-        np.savez(os.path.join(outdir, 'reduced.npz'), counts=counts, earliest=earliest)
+        np.savez(os.path.join(outdir, 'reduced.npz'), counts=counts, earliest=earliest, daq_t=daq_t, daq_q=daq_q, daq_h=daq_h)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,6 +89,10 @@ def test_two_rank_hit_reduction_equals_single_process(tmp_path, oracle_mod, tiny
     assert counts.sum() > 100
     assert np.array_equal(got['counts'].astype(np.uint32), counts)
     assert np.array_equal(got['earliest'], earliest)
+    t, q, hist, hit = oracle_mod.run_daq(tiny_packed, end, _daq_tables(), 1.0 / 64, seed=12345)
+    assert hit.sum() > 10
+    assert np.array_equal(got['daq_t'], t.view(np.uint32)) and np.array_equal(got['daq_h'], hist)
+    assert np.array_equal(got['daq_q'], np.rint(q * 64).astype(np.uint32))
 
 
 def test_allreduce_without_process_group_is_identity():
@@ -87,3 +102,7 @@ def test_allreduce_without_process_group_is_identity():
     e = np.array([0x7f800000, 5, 7], dtype=np.uint32)
     c2, e2 = allreduce_channel_hits(c, e)
     assert np.array_equal(c2, c) and np.array_equal(e2, e)
+    from chroma_amd.dist import allreduce_daq_channels
+    h = np.array([0, 0x84, 0x2], dtype=np.uint32)
+    e3, c3, h3 = allreduce_daq_channels(e, c, h)
+    assert np.array_equal(e3, e) and np.array_equal(c3, c) and np.array_equal(h3, h)
