@@ -213,3 +213,51 @@ def test_numpy_restatement_agrees_with_the_c_oracle(oracle_mod, tiny_packed):
         sigma = np.sqrt(a + b + 1.0)                          # two independent Poisson-like counts
         assert abs(a - b) < 5 * sigma, (name, a, b)
     assert not ((out.flags & (event.NO_HIT | event.NAN_ABORT)) != 0).any()
+
+
+def test_bulk_reemission_spectrum(oracle_mod):
+    """The intent of the reference's test/test_reemission.py:15-80 (skipped there, and written against
+    attributes Material no longer has): monoenergetic photons started inside a wavelength-shifting sphere
+    are absorbed and re-emitted, and the wavelengths that reach the detecting sphere follow the
+    component's re-emission CDF.  Here the material absorbs below 400 nm only, so a photon is
+    shifted once and then leaves."""
+    import scipy.stats
+    from chroma_amd.geometry import Geometry, Solid, Material, Surface, vacuum, standard_wavelengths
+    from chroma_amd.make import sphere
+    from chroma_amd.loader import create_geometry_from_obj
+    wl = standard_wavelengths.astype(float)
+    scint = Material('scint')
+    scint.set('refractive_index', 1.0)
+    absorb = np.where(wl < 400.0, 1.0, 1e7)      # the material's total; its one component takes all of it (photon.h:205-214)
+    scint.set('absorption_length', absorb)
+    scint.set('scattering_length', 1e7)
+    norm = scipy.stats.norm(loc=600.0, scale=50.0)
+    cdf = norm.cdf(wl)
+    cdf[wl <= 400.0] = 0.0                       # nothing re-emitted where the component still absorbs
+    cdf = (cdf - cdf.min()) / (cdf.max() - cdf.min())
+    tgrid = np.arange(0, 100, 0.05)
+    tcdf = 1.0 - np.exp(-tgrid / 5.0)
+    tcdf /= tcdf[-1]
+    for name, value in (('comp_reemission_prob', 1.0), ('comp_reemission_wvl_cdf', cdf),
+                        ('comp_absorption_length', absorb)):
+        tmp = Material('tmp'); tmp.set('x', value)
+        getattr(scint, name).append(tmp.x)
+    scint.comp_reemission_time_cdf.append(np.column_stack([tgrid, tcdf]).astype(np.float32))
+    detector = Surface('detector')
+    detector.set('detect', 1.0)
+    world = Geometry(vacuum)
+    world.add_solid(Solid(sphere(1000.0), vacuum, vacuum, surface=detector))
+    world.add_solid(Solid(sphere(500.0), scint, vacuum))
+    pk = pack_geometry(create_geometry_from_obj(world))
+    ph = bomb(40000, 21, wavelength=250.0)
+    out, _, _ = oracle_mod.propagate(pk, ph, seed=5, max_steps=20, nthreads=4)
+    hit = (out.flags & event.SURFACE_DETECT) != 0
+    assert hit.mean() > 0.95 and ((out.flags[hit] & event.BULK_REEMIT) != 0).all()
+    got = out.wavelengths[hit].astype(float)
+    assert got.min() >= 400.0 and abs(got.mean() - 600.0) < 2.0 and abs(got.std() - 50.0) < 2.0
+    # Kolmogorov-Smirnov against the tabulated CDF the engine samples (linear between the grid points)
+    ks = scipy.stats.kstest(got, lambda x: np.interp(x, wl, cdf))
+    assert ks.pvalue > 1e-3, ks
+    # and the re-emission is delayed by the component's decay time (5 ns) on top of the 1000 mm flight
+    flight = 1000.0 / 299.792458
+    assert abs((out.t[hit] - flight).mean() - 5.0) < 0.3
