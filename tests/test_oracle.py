@@ -261,3 +261,36 @@ def test_bulk_reemission_spectrum(oracle_mod):
     # and the re-emission is delayed by the component's decay time (5 ns) on top of the 1000 mm flight
     flight = 1000.0 / 299.792458
     assert abs((out.t[hit] - flight).mean() - 5.0) < 0.3
+
+
+def test_sample_cdf_reproduces_a_binned_gaussian(oracle_mod):
+    """The intent of the reference's test/test_sample_cdf.py:10-67 for the non-uniform CDF sampler
+    (chroma/cuda/random.h:28-31 over interpolate.h:33-58), which only the DAQ uses: draws through a
+    tabulated unit-Gaussian CDF follow that CDF (Kolmogorov probability > 0.01)."""
+    import scipy.stats
+    from chroma_amd.detector import Detector
+    from chroma_amd.geometry import Solid, vacuum
+    from chroma_amd.make import box
+    from chroma_amd.demo.optics import r7081hqe_photocathode
+    from chroma_amd.loader import create_geometry_from_obj
+    cube = Detector(vacuum)
+    cube.add_pmt(Solid(box(10.0, 10, 10), vacuum, vacuum, surface=r7081hqe_photocathode))
+    pk = pack_geometry(create_geometry_from_obj(cube))
+    n = 200
+    # (t = 100: a channel time below zero would lose the atomicMin on its bit pattern, daq.cu:5-12)
+    ph = Photons(np.zeros((n, 3)), np.tile([0, 0, 1.0], (n, 1)), np.tile([1.0, 0, 0], (n, 1)), np.full(n, 400.0), t=np.full(n, 100.0))
+    end, _, _ = oracle_mod.propagate(pk, ph, seed=2, max_steps=10)
+    one = int(np.flatnonzero(end.flags & event.SURFACE_DETECT)[0])
+    edges = np.linspace(-5.0, 5.0, 101).astype(np.float32)
+    cdf = scipy.stats.norm.cdf(edges).astype(np.float32)
+    cdf = (cdf - cdf[0]) / (cdf[-1] - cdf[0])
+    flat_x, flat_y = np.array([0.0, 1.0], dtype=np.float32), np.array([0.0, 1.0], dtype=np.float32)
+    draws = []
+    for k in range(3000):                         # one photon, a new acquisition (= a new stream) per draw
+        t, q, hist, hit = oracle_mod.run_daq(pk, end, (edges, cdf, flat_x, flat_y), 1.0 / 1024, seed=4, acquisition=k,
+                                             start_photon=one, nphotons=1)
+        draws.append(t[0] - end.t[one])
+    draws = np.asarray(draws, dtype=float)
+    assert abs(draws.mean()) < 0.06 and abs(draws.std() - 1.0) < 0.05
+    ks = scipy.stats.kstest(draws, lambda x: np.interp(x, edges, cdf))
+    assert ks.pvalue > 0.01, ks
