@@ -1,0 +1,12 @@
+#!/bin/bash
+# The host-side C++ (chroma_amd/csrc/{bvh_build,wide_build,mesh_utils}.cpp) under AddressSanitizer and UBSan
+# (CPU build only: the pool has no GPU sanitizer).  usage: tools/asan_host.sh
+set -e
+here=$(cd "$(dirname "$0")/.." && pwd)
+tmp=$(mktemp -d)
+g++ -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -fPIC -shared -pthread -ffp-contract=off \
+  -I$here/include $here/chroma_amd/csrc/bvh_build.cpp $here/chroma_amd/csrc/wide_build.cpp $here/chroma_amd/csrc/mesh_utils.cpp \
+  -o $tmp/libhost_asan.so
+CHROMA_ASAN_LIB=$tmp/libhost_asan.so LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) \
+  ASAN_OPTIONS=detect_leaks=0 python $here/tools/asan_host_driver.py
+rm -rf $tmp
