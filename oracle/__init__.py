@@ -36,6 +36,8 @@ def load(variant='contract'):
         return _libs[variant]
     name = {'contract': 'liboracle.so', 'libm': 'liboracle_libm.so'}[variant]
     path = os.path.join(_HERE, name)
+    if variant == 'contract' and os.environ.get('CHROMA_ORACLE_LIBRARY'):       # (a sanitizer build: tools/asan_host.sh)
+        path = os.environ['CHROMA_ORACLE_LIBRARY']
     if not os.path.exists(path):
         build()
     lib = ctypes.CDLL(path)
