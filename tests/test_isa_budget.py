@@ -1,0 +1,46 @@
+"""Compile-time properties of the hot kernels that the measured performance rests on (no GPU needed: hipcc
+cross-compiles gfx950): the ray cast keeps its state in registers -- no scratch -- at 7 waves per SIMD, the
+streaming kernels fit full occupancy.  tools/isa_report.sh is the same table for profiles/."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope='module')
+def isa_table():
+    if not os.path.exists('/opt/rocm/bin/hipcc') or shutil.which('c++filt') is None:
+        pytest.skip('hipcc / c++filt not available')
+    out = subprocess.run([os.path.join(ROOT, 'tools', 'isa_report.sh')], check=True, capture_output=True, text=True, timeout=900).stdout
+    table = {}
+    for line in out.splitlines():
+        if line.startswith('#') or not line.strip():
+            continue
+        name, vgpr, sgpr, scratch, lds, waves, code = [x.strip() for x in line.rsplit(',', 6)]
+        table[name.replace('void ', '')] = dict(vgpr=int(vgpr), scratch=int(scratch), lds=int(lds), waves=int(waves), code=int(code))
+    return table
+
+
+@pytest.mark.timeout(1000)
+def test_ray_cast_kernels_hold_their_state_in_registers(isa_table):
+    for name in ('k_raycast_quad<false>', 'k_raycast_quad<true>', 'k_raycast_coop<false>'):
+        k = isa_table[name]
+        assert k['scratch'] == 0 and k['waves'] == 7 and k['vgpr'] <= 72, (name, k)
+    assert isa_table['k_raycast_quad<false>']['lds'] <= 5 * 1024          # 28 waves per CU fit the 160 KB of LDS
+
+
+def test_streaming_kernels_run_at_full_occupancy(isa_table):
+    for name in ('k_ray_setup', 'k_load_working', 'k_store_working', 'k_step_begin', 'k_channel_hits', 'k_count_hits',
+                 'k_run_daq', 'k_run_daq_many', 'k_generate_bomb'):
+        k = isa_table[name]
+        assert k['scratch'] == 0 and k['waves'] == 8, (name, k)
+
+
+def test_every_kernel_of_the_path_is_in_the_table(isa_table):
+    for name in ('k_physics', 'k_tail_coop<false>', 'k_propagate<24, false>', 'k_raycast_retry<false>', 'k_raycast_wide<false>',
+                 'k_raycast_persistent<false>', 'k_distance_to_mesh<24, false>', 'k_copy_hits', 'k_daq_reset', 'k_daq_convert'):
+        assert name in isa_table, name
+    assert isa_table['k_physics']['waves'] >= 4
