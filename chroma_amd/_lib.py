@@ -68,7 +68,7 @@ class PropagateStats(Structure):
     """chroma_propagate_stats"""
     _fields_ = [('photon_steps', c_uint64), ('nodes_visited', c_uint64), ('triangles_tested', c_uint64),
                 ('launches', c_uint64), ('stack_overflows', c_uint64), ('kernel_ms', c_double),
-                ('raycast_ms', c_double), ('raycast_launches', c_uint64)]
+                ('raycast_ms', c_double), ('raycast_launches', c_uint64), ('stack_spills', c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -114,6 +114,7 @@ SIGNATURES = {
     'chroma_copy_photon_hits': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_uint32, POINTER(PhotonArrays),
                                           POINTER(PhotonArrays), c_void_p, POINTER(c_uint32)]),
     'chroma_distance_to_mesh': (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'chroma_intersect_mesh': (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'chroma_propagate': (c_int32, [c_void_p, c_void_p, POINTER(PhotonArrays), c_uint64, c_uint32, Rng, c_int32,
                                    c_int32, c_int32, c_int32, POINTER(PropagateStats), POINTER(c_int32)]),
     'chroma_channel_hits': (c_int32, [c_void_p, c_void_p, c_uint64, c_uint32, POINTER(PhotonArrays),
@@ -126,6 +127,7 @@ SIGNATURES = {
     'chroma_daq_convert': (c_int32, [c_void_p, c_uint32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'chroma_generate_bomb': (c_int32, [c_void_p, POINTER(PhotonArrays), c_uint64, c_uint64, c_uint64,
                                        POINTER(c_float), c_float, c_float]),
+    'chroma_probe': (c_int32, [c_void_p, c_int32, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32, c_float, c_float, c_void_p]),
     'chroma_bvh_build': (c_int32, [c_void_p, c_uint32, c_void_p, c_uint32, POINTER(c_float), c_float, c_int32,
                                    POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint32)]),
     'chroma_bvh_fetch': (c_int32, [c_void_p, c_void_p, c_void_p]),
@@ -135,6 +137,7 @@ SIGNATURES = {
                                     POINTER(c_uint32)]),
     'chroma_wide_data': (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     'chroma_wide_free': (c_int32, [c_void_p]),
+    'chroma_wide_validate': (c_int32, [c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_uint64]),
     'chroma_dedupe_vertices': (c_int32, [c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, POINTER(c_uint64)]),
     'chroma_propagate_stats_read': (c_int32, [c_void_p, POINTER(PropagateStats)]),
     'chroma_set_counting': (c_int32, [c_void_p, c_int32]),
@@ -143,36 +146,50 @@ SIGNATURES = {
 }
 
 _lib = None
+_variants = {}
 
 
 class ChromaError(RuntimeError):
     pass
 
 
-def load():
-    """Load libchroma_hip.so once; fail loudly when it is not there."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIBRARY_PATH):
+def _bind(path):
+    if not os.path.exists(path):
         raise ChromaError(
             'libchroma_hip.so is not built (%s missing).  Build it with '
             '`python -c "import __graft_entry__ as g; g.build()"` or `make -C chroma_amd/csrc`.  '
-            'There is no CPU fallback.' % LIBRARY_PATH)
+            'There is no CPU fallback.' % path)
     # torch ships its own libamdhip64 under the same SONAME; if it is going to be used in this
     # process it has to be loaded first so that both sides share one HIP runtime.
-    lib = ctypes.CDLL(LIBRARY_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError = symbol missing: also loud
         fn.restype = restype
         fn.argtypes = argtypes
-    _lib = lib
     return lib
 
 
-def check(rc):
+def load(path=None):
+    """Load libchroma_hip.so once; fail loudly when it is not there.  ``path`` names another build of
+    the same sources (build_variants/, kernel A/B experiments and the shallow-stack test variant): it
+    is loaded beside the product library and used by the contexts created with it."""
+    global _lib
+    if path is not None and os.path.abspath(path) != os.path.abspath(LIBRARY_PATH):
+        key = os.path.abspath(path)
+        if key not in _variants:
+            _variants[key] = _bind(key)
+        return _variants[key]
+    if _lib is None:
+        _lib = _bind(LIBRARY_PATH)
+    return _lib
+
+
+def check(rc, lib=None):
     if rc != 0:
-        msg = load().chroma_last_error()
+        msg = (lib or load()).chroma_last_error()
+        if not msg and lib is None:       # the call may have gone to a variant library (its own message buffer)
+            for v in _variants.values():
+                msg = msg or v.chroma_last_error()
         raise ChromaError('libchroma_hip error %d: %s' % (rc, msg.decode() if msg else '?'))
 
 
@@ -232,6 +249,16 @@ def wide_build(nodes, ntriangles):
                 'rank': copy(p[3], int(ntriangles)), 'depth': depth.value}
     finally:
         lib.chroma_wide_free(handle)
+
+
+def wide_validate(wide, ntriangles):
+    """True when the index checks chroma_geometry_create applies to a derived tree pass for ``wide``
+    (a dict as returned by wide_build, possibly tampered with by a test)."""
+    lib = load()
+    wn = np.ascontiguousarray(wide['wnodes'], dtype=np.uint32)
+    t2r = np.ascontiguousarray(wide['tri_to_record'], dtype=np.uint32)
+    r2t = np.ascontiguousarray(wide['record_to_tri'], dtype=np.uint32)
+    return lib.chroma_wide_validate(ptr(wn), wn.size // 32, ptr(t2r), int(ntriangles), ptr(r2t), len(r2t)) == 0
 
 
 def dedupe_vertices(vertices, triangles):

@@ -811,7 +811,7 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     if (inner && j != nj) {
                         int pos = sp + __popc(others & below);
                         if (pos < COOP_STACK) { stack_n[pos] = w; stack_t[pos] = t; }
-                        else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(w, __float_as_uint(t));
+                        else if (pos < COOP_STACK + COOP_SPILL) { spill[pos - COOP_STACK] = make_uint2(w, __float_as_uint(t)); if (COUNT) cnt.spills++; }
                     }
                     sp += __popc(others);
                     cur = (uint32_t)__shfl((int)w, (int)(gshift + nj));
@@ -873,10 +873,12 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
 
     if (COUNT) {
         unsigned long long st = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        unsigned long long sx = wave_sum_u64(cnt.spills);
         if (lane == 0) {
             atomicAdd(&counters->photon_steps, st);
             atomicAdd(&counters->nodes_visited, nd);
             atomicAdd(&counters->triangles_tested, tr);
+            if (sx) atomicAdd(&counters->stack_spills, sx);
         }
     }
 }
@@ -1111,12 +1113,12 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     {
                         if (qa) {
                             if (pos < COOP_STACK) { stack_n[pos] = ea.w; stack_t[pos] = ta; }
-                            else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(ea.w, __float_as_uint(ta));
+                            else if (pos < COOP_STACK + COOP_SPILL) { spill[pos - COOP_STACK] = make_uint2(ea.w, __float_as_uint(ta)); if (COUNT) atomicAdd(&counters->stack_spills, 1ull); }
                             pos++;
                         }
                         if (qb) {
                             if (pos < COOP_STACK) { stack_n[pos] = eb.w; stack_t[pos] = tb; }
-                            else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(eb.w, __float_as_uint(tb));
+                            else if (pos < COOP_STACK + COOP_SPILL) { spill[pos - COOP_STACK] = make_uint2(eb.w, __float_as_uint(tb)); if (COUNT) atomicAdd(&counters->stack_spills, 1ull); }
                         }
                         if (sp > COOP_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
                             triangle_index = HIT_RETRY;
@@ -1254,7 +1256,7 @@ __device__ inline int coop_cast(const GeoView &g, v3 origin, v3 direction, int l
                     if (inner && j != nj) {
                         int pos = sp + __popc(others & below);
                         if (pos < COOP_STACK) { stack_n[pos] = w; stack_t[pos] = t; }
-                        else if (pos < COOP_STACK + COOP_SPILL) spill[pos - COOP_STACK] = make_uint2(w, __float_as_uint(t));
+                        else if (pos < COOP_STACK + COOP_SPILL) { spill[pos - COOP_STACK] = make_uint2(w, __float_as_uint(t)); if (COUNT) cnt.spills++; }
                     }
                     sp += __popc(others);
                     cur = (uint32_t)__shfl((int)w, (int)(gshift + nj));
@@ -1411,10 +1413,12 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const float4 *work_in
 
     if (COUNT) {
         unsigned long long sts = wave_sum_u64(cnt.steps), nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        unsigned long long sx = wave_sum_u64(cnt.spills);
         if (lane == 0) {
             atomicAdd(&counters->photon_steps, sts);
             atomicAdd(&counters->nodes_visited, nd);
             atomicAdd(&counters->triangles_tested, tr);
+            if (sx) atomicAdd(&counters->stack_spills, sx);
         }
     }
 }
@@ -1872,8 +1876,8 @@ __global__ void k_daq_convert(uint32_t n, float charge_unit, const uint32_t *tim
 // distance_to_mesh (chroma/cuda/mesh.h:124-151)
 template <int LDS_N, bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
-k_distance_to_mesh(GeoView g, int nthreads, const float *origin, const float *direction, float *distance_out,
-                   int32_t *triangle_out, DeviceCounters *counters)
+k_distance_to_mesh(GeoView g, int nthreads, const float *origin, const float *direction, const int32_t *last_hit_in,
+                   float *distance_out, int32_t *triangle_out, DeviceCounters *counters)
 {
     __shared__ uint32_t s_lds[TRAV_LDS_WORDS(LDS_N, PROP_BLOCK)];
     int id = blockIdx.x * PROP_BLOCK + threadIdx.x;
@@ -1886,7 +1890,8 @@ k_distance_to_mesh(GeoView g, int nthreads, const float *origin, const float *di
         d = d / norm(d);
     }
     float dist;
-    int tri = intersect_mesh<LDS_N, PROP_BLOCK, COUNT>(g, o, d, dist, -1, s_lds + threadIdx.x, cnt, on);
+    const int last_hit = (on && last_hit_in) ? last_hit_in[id] : -1;
+    int tri = intersect_mesh<LDS_N, PROP_BLOCK, COUNT>(g, o, d, dist, last_hit, s_lds + threadIdx.x, cnt, on);
     if (on) {
         if (tri != -1) distance_out[id] = dist;
         if (triangle_out) triangle_out[id] = tri;
@@ -1922,6 +1927,29 @@ __global__ void k_generate_bomb(PhotonView pv, uint64_t n, uint64_t seed, uint64
     pv.weights[i] = 1.0f;
     pv.evidx[i] = 0u;
     pv.rng_counters[i] = 0u;
+}
+
+// chroma_probe: single device functions of the path, one call per element (tests pin them on the oracle
+// and on the reference's own headers compiled for gfx950 by the test infrastructure)
+__global__ void k_probe(int fn, uint64_t n, const float *x, const float *tab_x, const float *tab_f, uint32_t ntab,
+                        float start, float step, float *out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (fn == 0) {
+        GeoView g;
+        g.wavelength_n = ntab; g.wavelength_start = start; g.wavelength_step = step;
+        out[i] = interp_property(g, x[i], tab_f);
+    } else if (fn == 1) {
+        out[i] = interp_idx(x[i], (int)ntab, tab_x);
+    } else if (fn == 2) {
+        out[i] = interp_table(x[i], (int)ntab, tab_x, tab_f);
+    } else {
+        const float *p = x + 7 * i;
+        v3 r = rotate(mk3(p[0], p[1], p[2]), p[3], mk3(p[4], p[5], p[6]));
+        float *o = out + 5 * i;
+        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = cm_cosf(p[3]); o[4] = cm_sinf(p[3]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2130,11 +2158,13 @@ static uint32_t compute_stack_need(const uint32_t *nodes, size_t nnodes)
 // mesh.h:124-151 asks for the nearest triangle along free rays.  Same pipeline as a propagation step:
 // ray records, k_raycast_quad, the check that the reference tests the winner (record_hit_is_regular),
 // the literal reference walk for the rays that fail it or that the fast walk cannot take.
-__global__ void k_rays_from_arrays(GeoView g, int n, const float *origin_in, const float *direction_in, float4 *rays,
-                                   int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, StepState *st)
+__global__ void k_rays_from_arrays(GeoView g, int n, const float *origin_in, const float *direction_in, const int32_t *last_hit_in,
+                                   float4 *rays, int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, StepState *st)
 {
     int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
+    int last_hit = last_hit_in ? last_hit_in[slot] : -1;          // a triangle id (mesh.h:82) -> its record
+    last_hit = (last_hit >= 0 && (uint32_t)last_hit < g.ntriangles) ? (int)g.tri_to_dev[last_hit] : -1;
     v3 origin = load3(origin_in, slot), direction = load3(direction_in, slot);
     direction = direction / norm(direction);
     v3 noid = (-origin) / direction;
@@ -2149,7 +2179,7 @@ __global__ void k_rays_from_arrays(GeoView g, int n, const float *origin_in, con
                 cm_fmaf(g.world_origin[2], inv_dir.z, noid.z));
     }
     float4 *r = rays + 4 * (size_t)slot;
-    r[0] = make_float4(origin.x, origin.y, origin.z, __int_as_float(-1));
+    r[0] = make_float4(origin.x, origin.y, origin.z, __int_as_float(last_hit));
     r[1] = make_float4(direction.x, direction.y, direction.z, __int_as_float(status));
     r[2] = make_float4(a.x, a.y, a.z, 0.0f);
     r[3] = make_float4(b.x, b.y, b.z, 0.0f);
@@ -2198,8 +2228,8 @@ k_distance_retry(GeoView g, const float4 *rays, const StepState *st, const uint3
         const float4 *r = rays + 4 * (size_t)slot;
         const float4 r0 = r[0], r1 = r[1];
         float dist;
-        int rec = intersect_mesh_dev<STACK_LDS, PROP_BLOCK, COUNT>(g, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), dist, -1,
-                                                                   s_lds + threadIdx.x, cnt, true);
+        int rec = intersect_mesh_dev<STACK_LDS, PROP_BLOCK, COUNT>(g, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), dist,
+                                                                   __float_as_int(r0.w), s_lds + threadIdx.x, cnt, true);
         if (rec >= 0) distance_out[slot] = dist;
         if (triangle_out) triangle_out[slot] = rec >= 0 ? (int32_t)g.dev_to_tri[rec] : -1;
     }
@@ -2481,6 +2511,14 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     phase("nodes upload + wide tree");
     const std::vector<uint32_t> &tri_to_dev = wt.tri_to_dev, &dev_to_tri = wt.dev_to_tri;
     const size_t nrecords = dev_to_tri.size();
+    {   // the walks index the wide nodes and the records with what this tree holds: check it before any upload
+        std::string werr;
+        if (chroma_host::validate_wide_tree(wt.wnodes.data(), wt.nwide, tri_to_dev.data(), d->ntriangles, dev_to_tri.data(), nrecords, werr) != 0) {
+            chroma_geometry_destroy(g);
+            return set_error(CHROMA_ERR_INVALID, "%s", werr.c_str());
+        }
+    }
+    phase("wide tree index checks");
     { const uint4 *p; if ((rc = upload(g, (const uint4 *)wt.wnodes.data(), wt.nwide * 8, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } v.wnodes = p; }
     v.nwide = (uint32_t)wt.nwide;
     g->nwide = wt.nwide; g->wide_depth = wt.depth; g->nrecords = nrecords; g->wide_stack_need = wt.stack_need;
@@ -2759,10 +2797,16 @@ int chroma_copy_photon_hits(chroma_ctx *ctx, chroma_geometry *geom, int32_t firs
 
 static int ensure_queues(chroma_ctx *ctx, size_t n);
 static int distance_to_mesh_fast(chroma_ctx *ctx, chroma_geometry *geom, int32_t n, const float *d_origin,
-                                 const float *d_direction, float *d_distance, int32_t *d_triangle);
+                                 const float *d_direction, const int32_t *d_last_hit, float *d_distance, int32_t *d_triangle);
 
 int chroma_distance_to_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthreads, const float *d_origin,
                             const float *d_direction, float *d_distance, int32_t *d_triangle)
+{
+    return chroma_intersect_mesh(ctx, geom, nthreads, d_origin, d_direction, nullptr, d_distance, d_triangle);
+}
+
+int chroma_intersect_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthreads, const float *d_origin,
+                          const float *d_direction, const int32_t *d_last_hit, float *d_distance, int32_t *d_triangle)
 {
     if (!ctx || !geom || !d_origin || !d_direction || !d_distance) return set_error(CHROMA_ERR_INVALID, "bad argument");
     if (nthreads <= 0) return CHROMA_OK;
@@ -2770,10 +2814,10 @@ int chroma_distance_to_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthr
     if (need > STACK_LDS + STACK_SCRATCH)
         return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
     if (geom->view.wnodes && geom->wide_stack_need <= COOP_STACK + COOP_SPILL && ctx->wide_walk != CHROMA_WALK_REFERENCE)
-        return distance_to_mesh_fast(ctx, geom, nthreads, d_origin, d_direction, d_distance, d_triangle);
+        return distance_to_mesh_fast(ctx, geom, nthreads, d_origin, d_direction, d_last_hit, d_distance, d_triangle);
     dim3 grid((unsigned)((nthreads + PROP_BLOCK - 1) / PROP_BLOCK)), block(PROP_BLOCK);
 #define LAUNCH(N, C) hipLaunchKernelGGL((k_distance_to_mesh<N, C>), grid, block, 0, ctx->stream, geom->view, nthreads, \
-                                        d_origin, d_direction, d_distance, d_triangle, ctx->d_counters)
+                                        d_origin, d_direction, d_last_hit, d_distance, d_triangle, ctx->d_counters)
     if (ctx->counting) LAUNCH(STACK_LDS, true); else LAUNCH(STACK_LDS, false);
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
@@ -2781,7 +2825,7 @@ int chroma_distance_to_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthr
 }
 
 static int distance_to_mesh_fast(chroma_ctx *ctx, chroma_geometry *geom, int32_t n, const float *d_origin,
-                                 const float *d_direction, float *d_distance, int32_t *d_triangle)
+                                 const float *d_direction, const int32_t *d_last_hit, float *d_distance, int32_t *d_triangle)
 {
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_queues(ctx, (size_t)n); if (rc) return rc;
@@ -2791,7 +2835,7 @@ static int distance_to_mesh_fast(chroma_ctx *ctx, chroma_geometry *geom, int32_t
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_step_set, dim3(1), dim3(1), 0, ctx->stream, st, (uint32_t)n);
     hipLaunchKernelGGL(k_rays_from_arrays, dim3(blocks), dim3(256), 0, ctx->stream, geom->view, (int)n, d_origin, d_direction,
-                       ctx->rays, ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, st);
+                       d_last_hit, ctx->rays, ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, st);
     const unsigned waves = (unsigned)std::min<long long>(((long long)n + 15) / 16, (long long)ctx->quad_waves);
     if (ctx->counting)
         hipLaunchKernelGGL((k_raycast_quad<true>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, 0, st,
@@ -2852,6 +2896,7 @@ int chroma_propagate_stats_read(chroma_ctx *ctx, chroma_propagate_stats *stats)
     stats->nodes_visited += c.nodes_visited;
     stats->triangles_tested += c.triangles_tested;
     stats->stack_overflows += c.stack_overflows;
+    stats->stack_spills += c.stack_spills;
     return CHROMA_OK;
 }
 
@@ -3114,6 +3159,19 @@ int chroma_daq_convert(chroma_ctx *ctx, uint32_t nchannels, float charge_unit, c
     if (nchannels == 0) return CHROMA_OK;
     hipLaunchKernelGGL(k_daq_convert, dim3((nchannels + 255) / 256), dim3(256), 0, ctx->stream, nchannels, charge_unit,
                        d_earliest_time_int, d_channel_q_int, d_earliest_time, d_channel_q);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+int chroma_probe(chroma_ctx *ctx, int32_t fn, uint64_t n, const float *d_x, const float *d_tab_x, const float *d_tab_f,
+                 uint32_t ntab, float start, float step, float *d_out)
+{
+    if (!ctx || !d_x || !d_out || fn < 0 || fn > 3) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if ((fn == 0 && (!d_tab_f || ntab < 2)) || (fn == 1 && (!d_tab_x || ntab < 2)) || (fn == 2 && (!d_tab_x || !d_tab_f || ntab < 2)))
+        return set_error(CHROMA_ERR_INVALID, "probe %d: table missing", fn);
+    if (n == 0) return CHROMA_OK;
+    hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)fn, n, d_x, d_tab_x, d_tab_f,
+                       ntab, start, step, d_out);
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
 }

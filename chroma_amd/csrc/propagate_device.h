@@ -32,7 +32,7 @@ struct State {
     float distance_to_boundary;
 };
 
-struct LaneCounters { uint32_t steps, nodes, tris, overflows; };
+struct LaneCounters { uint32_t steps, nodes, tris, overflows, spills; };
 
 // ---- geometry.h -------------------------------------------------------------------------
 // interp_property (geometry.h:64-75); index clamped where the reference reads one past the

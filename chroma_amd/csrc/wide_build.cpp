@@ -633,6 +633,46 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
     return 0;
 }
 
+// What the device walks index with, checked before anything is uploaded: every inner child word names a
+// LATER wide node (so a walk terminates and the stack-need sweep above is right), every leaf word a
+// record inside the record table, every record a triangle of the mesh, every triangle a record that
+// names it back.  The buffers on the device are sized from exactly these counts (nwide * 128 bytes of
+// nodes, nrecords * 48 bytes of triangle records -- nrecords, not ntriangles: a triangle listed by
+// several leaves has several records), so a tree that passes cannot make a kernel read past them.
+int validate_wide_tree(const uint32_t *wnodes, size_t nwide, const uint32_t *tri_to_dev, uint32_t ntriangles,
+                       const uint32_t *dev_to_tri, size_t nrecords, std::string &err)
+{
+    if (!wnodes || nwide == 0) { err = "wide tree: no nodes"; return -1; }
+    if (nwide > 0x7FFFFFFFull || nrecords > 0x7FFFFFFFull) { err = "wide tree: more than 2^31 nodes or records"; return -1; }
+    if (nrecords < ntriangles) { err = "wide tree: fewer triangle records than triangles"; return -1; }
+    std::atomic<size_t> bad(SIZE_MAX);
+    auto note = [&](size_t i) { size_t cur = bad.load(); while (i < cur && !bad.compare_exchange_weak(cur, i)) {} };
+    parallel_for(nwide, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            const uint32_t *wn = wnodes + i * 32;
+            for (int j = 0; j < (int)WIDE_K; j++) {
+                const uint32_t w = wn[4 * j + 3];
+                if (w == WIDE_EMPTY) continue;
+                const bool ok = (w & WIDE_LEAF) ? (size_t)(w & ~WIDE_LEAF) < nrecords : ((size_t)w < nwide && (size_t)w > i);
+                if (!ok) { note(i); break; }
+            }
+        }
+    }, 1u << 14);
+    if (bad != SIZE_MAX) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "wide tree: node %zu has a child word outside the tree (%zu nodes, %zu records)", (size_t)bad, nwide, nrecords);
+        err = buf;
+        return -1;
+    }
+    parallel_for(nrecords, [&](size_t a, size_t b) { for (size_t k = a; k < b; k++) if (dev_to_tri[k] >= ntriangles) { note(k); break; } }, 1u << 16);
+    if (bad != SIZE_MAX) { err = "wide tree: a triangle record names a triangle outside the mesh"; return -1; }
+    parallel_for(ntriangles, [&](size_t a, size_t b) {
+        for (size_t t = a; t < b; t++) if (tri_to_dev[t] >= nrecords || dev_to_tri[tri_to_dev[t]] != t) { note(t); break; }
+    }, 1u << 16);
+    if (bad != SIZE_MAX) { err = "wide tree: a triangle has no record that names it"; return -1; }
+    return 0;
+}
+
 int wide_topology_from_env()
 {
     const char *e = getenv("CHROMA_TREE");
@@ -667,6 +707,14 @@ int chroma_wide_data(void *handle, const uint32_t **wnodes, const uint32_t **tri
     if (record_to_tri) *record_to_tri = t->dev_to_tri.data();
     if (rank) *rank = t->rank.data();
     return CHROMA_OK;
+}
+int chroma_wide_validate(const uint32_t *wnodes, uint64_t nwide, const uint32_t *tri_to_record, uint32_t ntriangles,
+                         const uint32_t *record_to_tri, uint64_t nrecords)
+{
+    if (!wnodes || !tri_to_record || !record_to_tri) return CHROMA_ERR_INVALID;
+    std::string err;
+    return chroma_host::validate_wide_tree(wnodes, (size_t)nwide, tri_to_record, ntriangles, record_to_tri, (size_t)nrecords, err) == 0
+               ? CHROMA_OK : CHROMA_ERR_INVALID;
 }
 int chroma_wide_free(void *handle)
 {

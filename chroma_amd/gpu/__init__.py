@@ -4,5 +4,5 @@ from chroma_amd.gpu.tools import (create_cuda_context, get_context, get_rng_stat
                                   device_count, empty, zeros, to_gpu)
 from chroma_amd.gpu.geometry import GPUGeometry, pack_geometry
 from chroma_amd.gpu.detector import GPUDetector
-from chroma_amd.gpu.photon import GPUPhotons, GPUPhotonsSlice
+from chroma_amd.gpu.photon import GPUPhotons, GPUPhotonsSlice, generate_bomb
 from chroma_amd.gpu.daq import GPUDaq, GPUChannels

@@ -7,8 +7,8 @@ from chroma_amd.gpu.tools import to_gpu
 
 
 class GPUDetector(GPUGeometry):
-    def __init__(self, detector, wavelengths=None, print_usage=False):
-        GPUGeometry.__init__(self, detector, wavelengths=wavelengths, print_usage=False)
+    def __init__(self, detector, wavelengths=None, print_usage=False, packed=None):
+        GPUGeometry.__init__(self, detector, wavelengths=wavelengths, print_usage=False, packed=packed)
         self.solid_id_to_channel_index_gpu = self._device_array('solid_id_to_channel_index', np.int32)
         self.nchannels = detector.num_channels()
         self.time_cdf_x_gpu = to_gpu(detector.time_cdf[0].astype(np.float32), ctx=self.ctx)

@@ -167,11 +167,14 @@ def pack_geometry(geometry, wavelengths=None, times=None):
 
 
 class GPUGeometry(object):
-    def __init__(self, geometry, wavelengths=None, times=None, print_usage=False, min_free_gpu_mem=300e6):
+    def __init__(self, geometry, wavelengths=None, times=None, print_usage=False, min_free_gpu_mem=300e6, packed=None):
         # min_free_gpu_mem controlled the reference's spill of BVH nodes to host memory
         # (chroma/gpu/geometry.py:211-230); with 288 GB of HBM everything stays on the device.
+        # ``packed``: a pack_geometry() result the caller already holds (and keeps): it is uploaded as
+        # it is and left whole instead of being packed a second time.
         self.ctx = get_context()
-        self.packed = pack_geometry(geometry, wavelengths=wavelengths, times=times)
+        keep_host_arrays = packed is not None
+        self.packed = packed if packed is not None else pack_geometry(geometry, wavelengths=wavelengths, times=times)
         handle = ctypes.c_void_p()
         _lib.check(self.ctx._lib.chroma_geometry_create(self.ctx.handle, ctypes.byref(self.packed.desc), ctypes.byref(handle)))
         self.handle = handle
@@ -188,8 +191,12 @@ class GPUGeometry(object):
         self.colors = self._device_array('colors', np.uint32)
         self.solid_id_map = self._device_array('solid_id_map', np.uint32)
         # host tables are not needed once uploaded, except the small ones tests look at
+        # (and the descriptor must not keep pointing at arrays that are gone)
         for big in ('vertices', 'triangles', 'nodes', 'material_codes', 'solid_id_map', 'colors'):
-            self.packed.arrays.pop(big, None)
+            if keep_host_arrays:
+                break
+            if self.packed.arrays.pop(big, None) is not None:
+                setattr(self.packed.desc, big, None)
         if print_usage:
             self.print_device_usage()
         logger.info(self.device_usage_str())

@@ -252,6 +252,20 @@ class GPUPhotons(object):
             yield view
 
 
+def generate_bomb(nphotons, seed, id_base=0, pos=(0.0, 0.0, 0.0), wavelength_lo=400.0, wavelength_hi=0.0, ctx=None):
+    """An isotropic photon bomb made ON THE DEVICE (chroma/benchmark.py:77-83 with the formulas of
+    chroma/sample.py:16-30; photon ``i`` draws from the Philox stream of ``0xB0B0... + id_base + i`` under
+    ``seed``): the source for batches too large to upload.  Returns a GPUPhotonsSlice; propagate it with
+    ``_lib.Rng(engine_seed, id_base)`` to give every photon the stream of its global id."""
+    ctx = ctx or get_context()
+    out = GPUPhotonsSlice(rng_counters=empty(nphotons, np.uint32, ctx), **_alloc_fields(nphotons, ctx))
+    s = _structure(out)
+    p = (ctypes.c_float * 3)(*[float(x) for x in pos])
+    _lib.check(ctx._lib.chroma_generate_bomb(ctx.handle, ctypes.byref(s), int(nphotons), int(seed), int(id_base), p,
+                                             float(wavelength_lo), float(wavelength_hi)))
+    return out
+
+
 class GPUPhotonsSlice(GPUPhotons):
     """A view of (or a set of freshly gathered) device photon arrays; same methods as
     GPUPhotons (chroma/gpu/photon.py:351-381)."""

@@ -48,8 +48,8 @@ class Context(object):
     a HIP context is not a stack object, so pop() only synchronises and makes the context
     no longer current for this module."""
 
-    def __init__(self, device_id=None):
-        lib = _lib.load()
+    def __init__(self, device_id=None, library=None):
+        lib = _lib.load(library)
         handle = ctypes.c_void_p()
         _lib.check(lib.chroma_init(-1 if device_id is None else int(device_id), ctypes.byref(handle)))
         self.handle = handle
@@ -99,9 +99,10 @@ class Context(object):
         return stats.as_dict()
 
 
-def create_cuda_context(device_id=None):
-    """Initialise the device and return the (now current) context."""
-    ctx = Context(device_id)
+def create_cuda_context(device_id=None, library=None):
+    """Initialise the device and return the (now current) context.  ``library``: path of another build
+    of libchroma_hip.so to run this context's calls through (tests, A/B experiments)."""
+    ctx = Context(device_id, library)
     ctx.push()
     return ctx
 

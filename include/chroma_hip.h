@@ -155,6 +155,8 @@ typedef struct chroma_propagate_stats {
     double   kernel_ms;          /* HIP-event time of the propagate kernel launches, if timed   */
     double   raycast_ms;         /* of which: the ray-cast kernel (k_raycast_persistent)         */
     uint64_t raycast_launches;   /* number of ray-cast launches timed in raycast_ms              */
+    uint64_t stack_spills;       /* stack entries pushed beyond the LDS part of a fast walk's stack
+                                    (counting mode only; the deep-stack path of the 4- and 8-lane walks) */
 } chroma_propagate_stats;
 
 const char *chroma_last_error(void);
@@ -228,6 +230,13 @@ int chroma_copy_photon_hits(chroma_ctx *ctx, chroma_geometry *geom, int32_t firs
 int chroma_distance_to_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthreads,
                             const float *d_origin, const float *d_direction,
                             float *d_distance, int32_t *d_triangle);
+/* The device function `intersect_mesh` (chroma/cuda/mesh.h:42-118) over a ray bundle, with its
+ * `last_hit_triangle` argument: ray i never hits triangle d_last_hit[i] (mesh.h:82; NULL or -1: no
+ * exclusion).  chroma_distance_to_mesh is this call with d_last_hit = NULL.  Same fast walk, check and
+ * literal-walk fallback as a propagation step. */
+int chroma_intersect_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthreads,
+                          const float *d_origin, const float *d_direction, const int32_t *d_last_hit,
+                          float *d_distance, int32_t *d_triangle);
 
 /* ---- fused host loops ---- */
 
@@ -294,6 +303,16 @@ int chroma_generate_bomb(chroma_ctx *ctx, const chroma_photon_arrays *photons, u
                          uint64_t seed, uint64_t id_base, const float pos[3],
                          float wavelength_lo, float wavelength_hi);
 
+/* Test probe: ONE call per element of a single device function of the propagate path, so that tests
+ * can pin the engine's own device code on the CPU oracle and on the reference's headers compiled for
+ * gfx950 (oracle/ref_headers_driver.hip).  All pointers are device pointers.
+ *   fn 0  interp_property (chroma/cuda/geometry.h:64-75)   d_x[n], d_tab_f[ntab], grid (start, step)
+ *   fn 1  interp_idx (chroma/cuda/interpolate.h:5-29)      d_x[n], d_tab_x[ntab]
+ *   fn 2  interp (chroma/cuda/interpolate.h:32-57)         d_x[n], d_tab_x[ntab], d_tab_f[ntab]
+ *   fn 3  rotate (chroma/cuda/rotate.h:22-28)              d_x[7 n] = a.xyz, phi, axis.xyz -> d_out[5 n] = r.xyz, cos phi, sin phi */
+int chroma_probe(chroma_ctx *ctx, int32_t fn, uint64_t n, const float *d_x, const float *d_tab_x, const float *d_tab_f,
+                 uint32_t ntab, float start, float step, float *d_out);
+
 /* ---- host-side BVH construction -------------------------------------------------------
  * Recursive-grid builder: replaces make_recursive_grid_bvh (chroma/bvh/grid.py:11-95) and the
  * kernels it drives -- make_leaves, make_parents_detailed, copy_and_offset, collapse_child
@@ -324,6 +343,12 @@ int chroma_wide_build(const uint32_t *nodes, uint64_t nnodes, uint32_t ntriangle
 int chroma_wide_data(void *handle, const uint32_t **wnodes, const uint32_t **tri_to_record,
                      const uint32_t **record_to_tri, const uint32_t **rank);
 int chroma_wide_free(void *handle);
+/* Index checks chroma_geometry_create runs on the derived tree before it uploads anything (every
+ * inner child word names a later wide node, every leaf word a record < nrecords, every record a
+ * triangle < ntriangles, every triangle a record that names it back): CHROMA_OK or CHROMA_ERR_INVALID.
+ * The device buffers are sized from exactly these counts, so a tree that passes cannot index past them. */
+int chroma_wide_validate(const uint32_t *wnodes, uint64_t nwide, const uint32_t *tri_to_record, uint32_t ntriangles,
+                         const uint32_t *record_to_tri, uint64_t nrecords);
 
 /* Merge identical vertices of a flattened mesh: replaces Mesh.remove_duplicate_vertices
  * (chroma/geometry.py:58-67, np.unique on a structured view) for large meshes.  The survivors

@@ -114,8 +114,9 @@ def propagate(packed, photons, seed, photon_id_base=0, max_steps=10, use_weights
     return hp.photons(), hp.rng_counters, stats.as_dict()
 
 
-def distance_to_mesh(packed, origins, directions, variant='contract'):
-    """(distance, triangle) for a ray bundle; misses give distance nan-filled here and triangle -1."""
+def distance_to_mesh(packed, origins, directions, variant='contract', last_hits=None):
+    """(distance, triangle) for a ray bundle; misses give distance nan-filled here and triangle -1.
+    ``last_hits``: per-ray triangle the ray must not hit (intersect_mesh's last_hit_triangle)."""
     lib = load(variant)
     o = np.ascontiguousarray(origins, dtype=np.float32)
     d = np.ascontiguousarray(directions, dtype=np.float32)
@@ -123,8 +124,12 @@ def distance_to_mesh(packed, origins, directions, variant='contract'):
     dist = np.full(n, np.nan, dtype=np.float32)
     tri = np.empty(n, dtype=np.int32)
     stats = _abi.PropagateStats()
-    lib.oracle_distance_to_mesh(ctypes.byref(packed.desc), n, o.ctypes.data, d.ctypes.data, dist.ctypes.data,
-                                tri.ctypes.data, ctypes.byref(stats))
+    lh = None if last_hits is None else np.ascontiguousarray(last_hits, dtype=np.int32)
+    lib.oracle_intersect_mesh.restype = c_int32
+    lib.oracle_intersect_mesh.argtypes = [POINTER(_abi.GeometryDesc), c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          POINTER(_abi.PropagateStats)]
+    lib.oracle_intersect_mesh(ctypes.byref(packed.desc), n, o.ctypes.data, d.ctypes.data, None if lh is None else lh.ctypes.data,
+                              dist.ctypes.data, tri.ctypes.data, ctypes.byref(stats))
     return dist, tri, stats.as_dict()
 
 
@@ -200,6 +205,27 @@ def math_fn(fn, x, y=None, variant='contract'):
     y = x if y is None else np.ascontiguousarray(y, dtype=np.float32)
     out = np.empty_like(x)
     rc = lib.oracle_math(names[fn], x.size, x.ctypes.data, y.ctypes.data, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+PROBES = {'interp_property': 0, 'interp_idx': 1, 'interp': 2, 'rotate': 3}
+
+
+def probe(fn, x, tab_x=None, tab_f=None, start=0.0, step=1.0, variant='contract'):
+    """One call per element of a single function of the path (oracle_probe).  'rotate': x is [n][7]
+    (a, phi, axis) and the result [n][5] (rotated vector, cos phi, sin phi)."""
+    lib = load(variant)
+    lib.oracle_probe.restype = c_int32
+    lib.oracle_probe.argtypes = [c_int32, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32, c_float, c_float, c_void_p]
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = len(x)
+    out = np.empty((n, 5) if fn == 'rotate' else n, dtype=np.float32)
+    tx = None if tab_x is None else np.ascontiguousarray(tab_x, dtype=np.float32)
+    tf = None if tab_f is None else np.ascontiguousarray(tab_f, dtype=np.float32)
+    ntab = len(tx) if tx is not None else (len(tf) if tf is not None else 0)
+    rc = lib.oracle_probe(PROBES[fn], n, x.ctypes.data, None if tx is None else tx.ctypes.data,
+                          None if tf is None else tf.ctypes.data, ntab, float(start), float(step), out.ctypes.data)
     assert rc == 0
     return out
 

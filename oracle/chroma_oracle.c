@@ -1018,8 +1018,9 @@ int oracle_propagate(const chroma_geometry_desc *g, const chroma_photon_arrays *
 }
 
 /* distance_to_mesh kernel (mesh.h:124-151) + the triangle id; misses leave distance untouched */
-int oracle_distance_to_mesh(const chroma_geometry_desc *g, uint64_t n, const float *origin, const float *direction,
-                            float *distance, int32_t *triangle, chroma_propagate_stats *stats)
+/* mesh.h:124-151 (last_hits == NULL), and intersect_mesh (mesh.h:42-118) with its last_hit_triangle argument */
+int oracle_intersect_mesh(const chroma_geometry_desc *g, uint64_t n, const float *origin, const float *direction,
+                          const int32_t *last_hits, float *distance, int32_t *triangle, chroma_propagate_stats *stats)
 {
     Counters cnt; memset(&cnt, 0, sizeof cnt);
     for (uint64_t i = 0; i < n; i++) {
@@ -1027,7 +1028,7 @@ int oracle_distance_to_mesh(const chroma_geometry_desc *g, uint64_t n, const flo
         f3 d = mk3(direction[3 * i], direction[3 * i + 1], direction[3 * i + 2]);
         d = div3s(d, norm3(d));
         float dist;
-        int tri = intersect_mesh(o, d, g, &dist, -1, &cnt);
+        int tri = intersect_mesh(o, d, g, &dist, last_hits ? last_hits[i] : -1, &cnt);
         if (tri != -1) distance[i] = dist;
         if (triangle) triangle[i] = tri;
     }
@@ -1037,6 +1038,12 @@ int oracle_distance_to_mesh(const chroma_geometry_desc *g, uint64_t n, const flo
         stats->stack_overflows += cnt.stack_overflows;
     }
     return 0;
+}
+
+int oracle_distance_to_mesh(const chroma_geometry_desc *g, uint64_t n, const float *origin, const float *direction,
+                            float *distance, int32_t *triangle, chroma_propagate_stats *stats)
+{
+    return oracle_intersect_mesh(g, n, origin, direction, NULL, distance, triangle, stats);
 }
 
 /* Test order of the reference walk: the loop of intersect_mesh (mesh.h:58-110) with EVERY box test
@@ -1196,6 +1203,37 @@ int oracle_math(int fn, uint64_t n, const float *x, const float *y, float *out)
         case 7: out[i] = M_ATAN2F(x[i], y[i]); break;
         case 8: out[i] = cm_sqrtf(x[i]); break;
         case 9: out[i] = cm_u32_to_uniform(cm_f2u(x[i])); break;
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
+/* Single functions of the path, one call per element, for the pins on the reference's own headers
+ * (oracle/ref_headers_driver.hip) and on the engine's device code (chroma_probe):
+ * fn 0 interp_property (geometry.h:64-75)   x[n], tab_f[ntab], grid (start, step)
+ * fn 1 interp_idx (interpolate.h:5-29)      x[n], tab_x[ntab]
+ * fn 2 interp (interpolate.h:32-57)         x[n], tab_x[ntab], tab_f[ntab]   (interp_table of the DAQ)
+ * fn 3 rotate (rotate.h:22-28)              x[7 n] = a.xyz, phi, axis.xyz -> out[5 n] = r.xyz, cos(phi), sin(phi) */
+static float interp_table(float x, int n, const float *xp, const float *fp);
+int oracle_probe(int fn, uint64_t n, const float *x, const float *tab_x, const float *tab_f, uint32_t ntab,
+                 float start, float step, float *out)
+{
+    chroma_geometry_desc g;
+    memset(&g, 0, sizeof g);
+    g.wavelength_n = ntab; g.wavelength_start = start; g.wavelength_step = step;
+    for (uint64_t i = 0; i < n; i++) {
+        switch (fn) {
+        case 0: out[i] = interp_property(&g, x[i], tab_f); break;
+        case 1: out[i] = interp_idx(x[i], (int)ntab, tab_x); break;
+        case 2: out[i] = interp_table(x[i], (int)ntab, tab_x, tab_f); break;
+        case 3: {
+            const float *p = x + 7 * i;
+            f3 r = rotate3(mk3(p[0], p[1], p[2]), p[3], mk3(p[4], p[5], p[6]));
+            float *o = out + 5 * i;
+            o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = M_COSF(p[3]); o[4] = M_SINF(p[3]);
+            break;
+        }
         default: return -1;
         }
     }

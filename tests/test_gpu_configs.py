@@ -1,0 +1,198 @@
+"""Parity on the geometries BASELINE.json quotes its numbers on (configs C2, C3, C5), on a real MI355X.
+
+For each: a 1e6-photon Philox bomb propagated to completion by the HIP engine (through the C ABI) and
+by the CPU oracle with the same per-photon streams -- flags, hit triangles, draw counters and every
+float field bit for bit -- and then the configuration's FULL batch size through properties that do not
+need the oracle: every photon terminal, per-channel counts add up to the flat-hit count, a second run
+is identical, the 4-lane walk over the 8-wide tree agrees with the literal reference walk over the
+reference tree on a slice.  C3 is the geometry whose wide tree needs more stack entries (60) than a
+ray keeps in LDS (24): the counting build reports how many entries went through the global spill area.
+
+The geometries are built here from chroma_amd.demo (no fixture file could hold 170 M triangles); the
+oracle runs on the host cores of the GPU box.
+"""
+import ctypes
+import gc
+import os
+
+import numpy as np
+import pytest
+
+from chroma_amd import event
+from test_gpu_parity import assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+ENGINE_SEED = 12345
+TERMINAL = event.NO_HIT | event.BULK_ABSORB | event.SURFACE_DETECT | event.SURFACE_ABSORB | event.NAN_ABORT
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    from chroma_amd import gpu as g
+    ctx = g.create_cuda_context(0)
+    yield g
+    ctx.pop()
+
+
+class Config(object):
+    """A demo geometry flattened, packed once (the oracle reads the packed arrays, the device gets the
+    same ones) and uploaded."""
+
+    def __init__(self, gpu, builder):
+        from chroma_amd import demo
+        from chroma_amd.loader import create_geometry_from_obj
+        from chroma_amd.gpu.geometry import pack_geometry
+        self.geometry = create_geometry_from_obj(getattr(demo, builder)())
+        self.packed = pack_geometry(self.geometry)
+        self.gg = gpu.GPUDetector(self.geometry, packed=self.packed)
+
+    def close(self):
+        self.gg = self.packed = self.geometry = None
+        gc.collect()
+
+
+@pytest.fixture(scope='module')
+def c3(gpu):
+    cfg = Config(gpu, 'detector29k')
+    yield cfg
+    cfg.close()
+
+
+@pytest.fixture(scope='module')
+def c2(gpu):
+    cfg = Config(gpu, 'detector')
+    yield cfg
+    cfg.close()
+
+
+@pytest.fixture(scope='module')
+def c5(gpu):
+    cfg = Config(gpu, 'scintillator_stress')
+    yield cfg
+    cfg.close()
+
+
+def propagate_device_bomb(gpu, cfg, n, id_base, wavelength=400.0, max_steps=100, counting=False, walk=None):
+    """n bomb photons generated on the device with global ids id_base.., propagated with those streams."""
+    from chroma_amd import _lib
+    ctx = gpu.get_context()
+    gp = gpu.generate_bomb(n, ENGINE_SEED, id_base=id_base, wavelength_lo=wavelength)
+    stats = {}
+    if walk:
+        ctx.set_walk(walk)
+    ctx.set_counting(counting)
+    try:
+        gp.propagate(cfg.gg, _lib.Rng(ENGINE_SEED, id_base), max_steps=max_steps, stats=stats)
+    finally:
+        ctx.set_counting(False)
+        if walk:
+            ctx.set_walk('quad')
+    return gp, stats
+
+
+def oracle_parity(gpu, oracle_mod, cfg, n, what, wavelength=400.0, id_base=0):
+    """The engine on a device-made bomb against the oracle on the oracle-made one (the two generators
+    must agree as well)."""
+    gp, stats = propagate_device_bomb(gpu, cfg, n, id_base, wavelength=wavelength, counting=True)
+    got = gp.get()
+    ph = oracle_mod.generate_bomb(n, seed=ENGINE_SEED, id_base=id_base, wavelength_lo=wavelength)
+    want, counters, ostats = oracle_mod.propagate(cfg.packed, ph, seed=ENGINE_SEED, photon_id_base=id_base, max_steps=100,
+                                                  nthreads=min(os.cpu_count() or 1, 64))
+    assert_bit_exact(got, want, what)
+    assert np.array_equal(gp.rng_counters.get(), counters), '%s: draw counters differ' % what
+    assert stats['photon_steps'] == ostats['photon_steps']
+    assert stats['launches'] == ostats['launches']
+    assert (got.flags & TERMINAL != 0).mean() > 0.999
+    return gp, got, stats, ostats
+
+
+def batch_properties(gpu, cfg, n, id_base, wavelength=400.0):
+    """What must hold for a batch of any size: all terminal (max_steps=100 leaves a handful at most),
+    the per-channel counts sum to the number of flat hits, the compaction returns that many photons
+    on valid channels, and a second run of the same photons gives the same bits."""
+    from chroma_amd import _lib
+    ctx = gpu.get_context()
+    gp, stats = propagate_device_bomb(gpu, cfg, n, id_base, wavelength=wavelength)
+    lib = ctx._lib
+    alive = ctypes.c_uint32()
+    flags = gp.flags.get()
+    n_alive = int(np.count_nonzero((flags & TERMINAL) == 0))
+    assert n_alive <= 1e-5 * n + 2, 'photons still alive after 100 steps: %d' % n_alive
+    assert not (flags & event.NAN_ABORT).any()
+    counts, earliest = gp.channel_hits(cfg.gg)
+    c = counts.get()
+    nhits = ctypes.c_uint32()
+    s = gpu.photon._structure(gp)
+    _lib.check(lib.chroma_count_photon_hits(ctx.handle, cfg.gg.handle, 0, n, event.SURFACE_DETECT, ctypes.byref(s), ctypes.byref(nhits)))
+    assert int(c.astype(np.uint64).sum()) == nhits.value > 0
+    det = np.count_nonzero(flags & event.SURFACE_DETECT)
+    assert nhits.value <= det
+    hits = gp.get_flat_hits(cfg.gg)
+    assert len(hits) == nhits.value
+    assert hits.channel.max() < cfg.gg.nchannels and (hits.flags & event.SURFACE_DETECT != 0).all()
+    assert np.array_equal(np.bincount(hits.channel.astype(np.int64), minlength=cfg.gg.nchannels).astype(np.uint32), c)
+    e = earliest.get().view(np.float32)
+    k = int(np.argmax(c))
+    assert e[k] == hits.t[hits.channel == k].min()
+    # a second run of the same photons: the same bits whatever order the queues took
+    t1, tri1, x1 = gp.t.get(), gp.last_hit_triangles.get(), gp.pos.get()
+    del gp
+    gp2, _ = propagate_device_bomb(gpu, cfg, n, id_base, wavelength=wavelength)
+    assert np.array_equal(gp2.flags.get(), flags)
+    assert np.array_equal(gp2.last_hit_triangles.get(), tri1)
+    assert np.array_equal(gp2.t.get().view(np.uint32), t1.view(np.uint32))
+    assert np.array_equal(gp2.pos.get().view(np.uint32), x1.view(np.uint32))
+    return stats, nhits.value
+
+
+def walks_agree(gpu, cfg, n, id_base, wavelength=400.0, walks=('reference',)):
+    """The 4-lane walk over the 8-wide tree against the other walks (default: the literal reference
+    walk over the reference tree) on one batch."""
+    gp, _ = propagate_device_bomb(gpu, cfg, n, id_base, wavelength=wavelength)
+    want = gp.get()
+    del gp
+    for walk in walks:
+        gp, _ = propagate_device_bomb(gpu, cfg, n, id_base, wavelength=wavelength, walk=walk)
+        assert_bit_exact(gp.get(), want, '%s walk vs quad' % walk)
+        del gp
+
+
+# ---- C3: 29 007 PMTs, 170 M triangles (BASELINE.json configs[2]) --------------------------------------
+def test_c3_one_million_photons_match_the_oracle(gpu, oracle_mod, c3):
+    assert c3.gg.stack_need() > 24            # deeper than the LDS part of a ray's stack: the spill path exists here
+    gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c3, 1_000_000, 'C3 29k PMTs, 1e6 photons')
+    # the wide walk fetches whole 8-entry nodes and tests fewer triangles than the reference's
+    assert 0 < stats['nodes_visited'] <= 2.0 * ostats['nodes_visited']
+    assert 0 < stats['triangles_tested'] <= 1.3 * ostats['triangles_tested']
+    print('C3 1e6: %d stack entries went through the global spill area' % stats['stack_spills'])
+    assert 0.03 < np.count_nonzero(got.flags & event.SURFACE_DETECT) / 1e6 < 0.15
+
+
+def test_c3_full_batch_properties(gpu, c3):
+    """1e8 photons (the batch bench.py times): properties + 1e7 of them through the reference walk."""
+    stats, nhits = batch_properties(gpu, c3, 100_000_000, id_base=1 << 32)
+    assert 0.03 < nhits / 1e8 < 0.15
+    walks_agree(gpu, c3, 10_000_000, id_base=1 << 32)
+
+
+# ---- C2: demo.detector(), 10 055 PMTs, 59 M triangles (configs[1]) -----------------------------------------
+def test_c2_one_million_photons_match_the_oracle(gpu, oracle_mod, c2):
+    gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c2, 1_000_000, 'C2 demo.detector(), 1e6 photons')
+    assert 0.03 < np.count_nonzero(got.flags & event.SURFACE_DETECT) / 1e6 < 0.15
+    walks_agree(gpu, c2, 1_000_000, id_base=0, walks=('coop', 'wide', 'reference'))
+
+
+def test_c2_batch_properties(gpu, c2):
+    batch_properties(gpu, c2, 10_000_000, id_base=1 << 33)
+
+
+# ---- C5: scintillator + WLS + dichroic + thin film (configs[4]) ----------------------------------------------
+def test_c5_one_million_photons_match_the_oracle(gpu, oracle_mod, c5):
+    gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c5, 1_000_000, 'C5 stress, 1e6 photons', wavelength=350.0)
+    assert int(np.bitwise_or.reduce(got.flags)) & 0x3FE == 0x3FE          # every physics flag reached
+
+
+def test_c5_full_batch_properties(gpu, c5):
+    batch_properties(gpu, c5, 10_000_000, id_base=1 << 34, wavelength=350.0)
+    walks_agree(gpu, c5, 2_000_000, id_base=1 << 34, wavelength=350.0, walks=('coop', 'reference'))

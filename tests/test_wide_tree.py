@@ -168,3 +168,38 @@ def test_build_is_repeatable():
             for key in ('wnodes', 'tri_to_record', 'record_to_tri', 'rank'):
                 assert np.array_equal(a[key], b[key]), (topology, key)
             assert a['depth'] == b['depth']
+
+
+def test_index_checks_reject_a_tampered_tree():
+    """chroma_geometry_create uploads a derived tree only after chroma_wide_validate's checks: every
+    inner child word names a later wide node, every leaf word a record inside the record table, every
+    record a triangle of the mesh, every triangle a record that names it back.  (The device buffers
+    are sized from these counts, so a tree that passes cannot make a kernel read past them -- the class
+    of fault DESIGN.md section 4a describes.)"""
+    for name, g in _geometries():
+        if name != 'tiny':
+            continue
+        ntri = len(g.mesh.triangles)
+        w = _wide(np.ascontiguousarray(g.bvh.nodes), ntri, 'sah')
+        assert _lib.wide_validate(w, ntri)
+        ent = w['wnodes'].reshape(-1, 4)
+        inner = np.flatnonzero((ent[:, 3] & LEAF) == 0)
+        leaf = np.flatnonzero(((ent[:, 3] & LEAF) != 0) & (ent[:, 3] != EMPTY))
+
+        def tampered(**kw):
+            t = {k: v.copy() for k, v in w.items() if isinstance(v, np.ndarray)}
+            for k, f in kw.items():
+                f(t[k])
+            return t
+        nwide, nrec = len(w['wnodes']), len(w['record_to_tri'])
+        # a child word past the node array / pointing backwards (a cycle) / a record past the table
+        assert not _lib.wide_validate(tampered(wnodes=lambda a: a.reshape(-1, 4).__setitem__((inner[5], 3), nwide)), ntri)
+        assert not _lib.wide_validate(tampered(wnodes=lambda a: a.reshape(-1, 4).__setitem__((inner[-1], 3), 0)), ntri)
+        assert not _lib.wide_validate(tampered(wnodes=lambda a: a.reshape(-1, 4).__setitem__((leaf[7], 3), LEAF | nrec)), ntri)
+        # a record naming a triangle outside the mesh; a triangle whose record names another one
+        assert not _lib.wide_validate(tampered(record_to_tri=lambda a: a.__setitem__(3, ntri)), ntri)
+        assert not _lib.wide_validate(tampered(tri_to_record=lambda a: a.__setitem__(0, a[1])), ntri)
+        # fewer records than triangles (the record table would be shorter than the ids the kernels read)
+        short = tampered()
+        short['record_to_tri'] = short['record_to_tri'][:-1]
+        assert not _lib.wide_validate(short, ntri)
