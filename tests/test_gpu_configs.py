@@ -194,7 +194,8 @@ def test_c5_full_batch_matches_the_oracle(gpu, oracle_mod, c5):
     oracle fast enough): bulk re-emission, thin film, WLS, dichroic and default surfaces, bit for bit --
     including the few photons the reference's arithmetic turns into NaN (NAN_ABORT, propagate.cu:270-273;
     e.g. a specular reflection at exactly normal incidence, photon.h:365-377)."""
-    gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c5, 10_000_000, 'C5 stress, 1e7 photons', wavelength=350.0)
+    gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c5, 10_000_000, 'C5 stress, 1e7 photons', wavelength=350.0,
+                                           id_base=1 << 34)          # (the batch test_c5_full_batch_properties runs)
     assert int(np.bitwise_or.reduce(got.flags)) & 0x3FE == 0x3FE          # every physics flag reached
     n_nan = int(np.count_nonzero(got.flags & event.NAN_ABORT))
     print('C5 1e7: %d NAN_ABORT photons (same ones in the oracle)' % n_nan)
