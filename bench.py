@@ -1,19 +1,25 @@
 #!/usr/bin/env python
 """bench.py -- photons/s of the propagate_hit path on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic photons already resident in
-HBM: GPUPhotons.propagate to completion (max_steps) + per-channel hit reduction + flat-hit
-count (+ the RCCL all-reduce of the per-channel arrays when more than one GPU runs).
+One "step" = one pass of the hot path over one batch of synthetic photons already resident in HBM:
+GPUPhotons.propagate to completion (max_steps) + per-channel hit reduction (count + earliest time) +
+flat-hit count and compaction (get_flat_hits' two kernels) + -- with more than one GPU -- the RCCL
+all-reduce of the per-channel arrays inside the library, + the read-back of those two small arrays.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|detector|lite|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|detector|lite|tiny|c5]
 
-For N > 1 the driver launches one rank per GPU through torch.distributed.run; every rank builds
-the (replicated) geometry, generates its own photon shard on the device (Philox stream keyed by
-the global photon id) and the per-GPU work is fixed (weak scaling).  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU (the driver starts them through torch.distributed.run; started by hand with
+--gpus N and no WORLD_SIZE, this script starts that launcher itself as a child process).  Local rank 0
+builds the geometry, its BVH and the derived wide tree ONCE and publishes them under /dev/shm; the
+other ranks map the same files.  Every rank generates its own photon shard on the device (Philox
+stream keyed by the GLOBAL photon id) and the per-GPU work is fixed (weak scaling); at N = 8 the c3
+shard is 1.25e8 photons (BASELINE.json configs[3]: 1e9 photons over 8 GPUs).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,14 +29,16 @@ if ROOT not in sys.path:
 
 CONFIGS = {
     # name: (builder, photons per GPU per step, description)
-    'c3': ('detector29k', 100_000_000, '29k-PMT sphere (29 007 PMTs, ~170 M triangles), 1e8-photon 400 nm bomb per GPU per step'),
-    'detector': ('detector', 10_000_000, 'demo.detector() (10 055 PMTs, 59 M triangles), 1e7-photon 400 nm bomb'),
-    'lite': ('detector_lite', 10_000_000, 'C2-lite (501 PMTs, ~3 M triangles), 1e7-photon 400 nm bomb'),
-    'tiny': ('tiny', 1_000_000, 'demo.tiny() (53 PMTs, 390 k triangles), 1e6-photon 400 nm bomb'),
-    'c5': ('scintillator_stress', 10_000_000, 'scintillator cube with thin-film / WLS / dichroic / detecting faces, 1e7-photon 350 nm bomb'),
+    'c3': ('detector29k', 100_000_000, '29k-PMT sphere (29 007 PMTs, ~170 M triangles), %s-photon 400 nm bomb per GPU per step'),
+    'detector': ('detector', 10_000_000, 'demo.detector() (10 055 PMTs, 59 M triangles), %s-photon 400 nm bomb'),
+    'lite': ('detector_lite', 10_000_000, 'C2-lite (501 PMTs, ~3 M triangles), %s-photon 400 nm bomb'),
+    'tiny': ('tiny', 1_000_000, 'demo.tiny() (53 PMTs, 390 k triangles), %s-photon 400 nm bomb'),
+    'c5': ('scintillator_stress', 10_000_000, 'scintillator cube with thin-film / WLS / dichroic / detecting faces, %s-photon 350 nm bomb'),
 }
+C4_PHOTONS_PER_GPU = 125_000_000      # configs[3]: 1e9 photons sharded over 8 GPUs
 ENGINE_SEED = 12345
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+RAYCAST_KERNEL = {'reference': 'k_raycast_persistent', 'wide': 'k_raycast_wide', 'coop': 'k_raycast_coop'}.get(os.environ.get('CHROMA_WALK', ''), 'k_raycast_quad')
 
 
 def log(*a):
@@ -38,7 +46,28 @@ def log(*a):
         print('[bench]', *a, file=sys.stderr, flush=True)
 
 
-RAYCAST_KERNEL = {'reference': 'k_raycast_persistent', 'wide': 'k_raycast_wide', 'coop': 'k_raycast_coop'}.get(os.environ.get('CHROMA_WALK', ''), 'k_raycast_quad')
+def kernel_source_hash():
+    """Identifies the kernels a profile was taken with: profiles/pmc_traffic.json entries carry it, and a
+    counter figure is only quoted when it belongs to the sources this run was built from."""
+    h = hashlib.sha256()
+    for name in ('chroma_hip.hip', 'propagate_device.h', 'device_common.h'):
+        with open(os.path.join(ROOT, 'chroma_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    with open(os.path.join(ROOT, 'include', 'chroma_math.h'), 'rb') as f:
+        h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def effective_cores():
+    """Host threads this process may really use: the affinity mask, capped by the cgroup's CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def main():
@@ -54,14 +83,24 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started by hand: become the launcher's parent BEFORE anything touches a GPU (a child process, never an exec)
+        import socket
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1 and 'CHROMA_HOST_THREADS' not in os.environ:
-        # every rank builds the same geometry on the same host at the same time: share the cores
-        os.environ['CHROMA_HOST_THREADS'] = str(max(4, (os.cpu_count() or 8) // int(os.environ.get('LOCAL_WORLD_SIZE', world))))
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (start one rank per GPU: python -m torch.distributed.run '
+                         '--nproc-per-node N bench.py --gpus N ...)' % (args.gpus, world))
 
-    # torch first: it carries its own libamdhip64 under the same SONAME, so loading it before
+    # torch first: it carries its own libamdhip64 (and RCCL) under the same SONAMEs, so loading it before
     # libchroma_hip.so makes both share one HIP runtime in this process.
     torch = None
     try:
@@ -75,49 +114,99 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
+    import ctypes
     import numpy as np
-    from chroma_amd import demo, gpu, event
+    from chroma_amd import demo, gpu, event, _lib
     from chroma_amd.loader import create_geometry_from_obj
     from chroma_amd.gpu.geometry import pack_geometry
-    from chroma_amd.gpu.photon import _structure
-    from chroma_amd.gpu.tools import GPUArray, zeros
-    from chroma_amd import _lib
-    import ctypes
+    from chroma_amd.gpu.photon import _structure, _alloc_fields, GPUPhotonsSlice
+    from chroma_amd.gpu.tools import GPUArray, zeros, empty
+    from chroma_amd.dist import init_comm, publish_packed_geometry, remove_published
 
     builder, nphotons, desc = CONFIGS[args.config]
     if args.photons:
         nphotons = args.photons
+    elif args.config == 'c3' and world == 8:
+        nphotons = C4_PHOTONS_PER_GPU
+    desc = desc % ('%.3g' % nphotons)
 
+    # ---- geometry: built once per node, uploaded by every rank ---------------------------------------------
     t0 = time.time()
-    geo = create_geometry_from_obj(getattr(demo, builder)())
+
+    def build_packed():
+        geo = create_geometry_from_obj(getattr(demo, builder)())
+        return pack_geometry(geo).attach_wide_tree()
+    shm_path = None
+    if world > 1:
+        packed, shm_path = publish_packed_geometry(build_packed, 'bench_' + args.config, local_rank, dist.barrier)
+        # the uploads (validation, staging) run in every rank at once: share the cores from here on
+        os.environ.setdefault('CHROMA_HOST_THREADS', str(max(4, effective_cores() // max(1, local_world))))
+    else:
+        packed = build_packed()
     t_build = time.time() - t0
-    log('%s: %d triangles, %d nodes, %d channels; built in %.1f s' % (
-        args.config, len(geo.mesh.triangles), len(geo.bvh.nodes), geo.num_channels(), t_build))
+    d = packed.desc
+    log('%s: %d triangles, %d nodes, %d wide nodes, %d channels; %s in %.1f s' % (
+        args.config, d.ntriangles, d.nnodes, d.nwide, d.nchannels,
+        'built + wide tree' if (world == 1 or local_rank == 0) else 'mapped from /dev/shm', t_build))
 
     ctx = gpu.create_cuda_context(local_rank)
     t0 = time.time()
-    packed_for_cpu = pack_geometry(geo) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    gg = gpu.GPUDetector(geo)
-    log('device: %s; geometry upload %.1f s; traversal stack need %d' % (ctx.device_name(), time.time() - t0, gg.stack_need()))
+    gg = gpu.GPUDetector.from_packed(packed)
+    if world > 1:
+        init_comm(ctx)
+        remove_published(shm_path, local_rank, dist.barrier)
+    elif os.environ.get('CHROMA_BENCH_COMM'):         # one-rank communicator: exercises the RCCL path on a 1-GPU box
+        ident = (ctypes.c_uint8 * 128)()
+        _lib.check(ctx._lib.chroma_comm_unique_id(ident))
+        _lib.check(ctx._lib.chroma_comm_init(ctx.handle, 1, 0, ident))
+    t_upload = time.time() - t0
+    log('device: %s; geometry upload %.1f s; traversal stack need %d' % (ctx.device_name(), t_upload, gg.stack_need()))
+    run_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if not run_cpu:
+        packed = None                 # (the host arrays are only needed again by the CPU baseline)
 
     lib = ctx._lib
     nbatches = args.warmup + args.steps
     wl_lo, wl_hi = (350.0 if args.config == 'c5' else 400.0), args.wavelength_hi
+    nch = gg.nchannels
+
+    # batches resident in HBM before the timed region -- unless that many do not fit: then a small ring of
+    # buffers is refilled by the device bomb generator INSIDE the timed region (counted against the result)
+    free, total = ctx.mem_get_info()
+    work_bytes = nphotons * (2 * 4 + 2 * 4 + 4 + 64 + 2 * 64) + (1 << 30)        # queues, hit hand-off, ray records, working sets
+    batch_bytes = nphotons * 64
+    resident = (nbatches + 1) * batch_bytes + work_bytes + int(0.12 * nphotons) * 72 < 0.92 * free
+    nbuffers = nbatches if resident else 2
+    log('HBM: %.1f GB free of %.1f; %d batches of %.1f GB %s' % (free / 1e9, total / 1e9, nbatches, batch_bytes / 1e9,
+        'resident' if resident else 'do not fit: %d buffers refilled inside the timed region' % nbuffers))
 
     class Batch(object):
         """Device photon arrays filled by the on-device bomb generator."""
-        def __init__(self, index):
-            from chroma_amd.gpu.tools import vec, empty
-            n = nphotons
-            self.pos, self.dir, self.pol = empty(n, vec.float3, ctx), empty(n, vec.float3, ctx), empty(n, vec.float3, ctx)
-            self.wavelengths, self.t, self.weights = empty(n, np.float32, ctx), empty(n, np.float32, ctx), empty(n, np.float32, ctx)
-            self.flags, self.evidx, self.rng_counters = empty(n, np.uint32, ctx), empty(n, np.uint32, ctx), empty(n, np.uint32, ctx)
-            self.last_hit_triangles = empty(n, np.int32, ctx)
-            self.struct = _structure(self)
+        def __init__(self):
+            self.ph = GPUPhotonsSlice(rng_counters=empty(nphotons, np.uint32, ctx), **_alloc_fields(nphotons, ctx))
+            self.struct = _structure(self.ph)
+            self.id_base = None
+
+        def fill(self, index):
             # global photon ids: batch-major, then rank, then index -> independent of world size
-            self.id_base = (index * world + rank) * n
+            self.id_base = (index * world + rank) * nphotons
             pos = (ctypes.c_float * 3)(0.0, 0.0, 0.0)
-            _lib.check(lib.chroma_generate_bomb(ctx.handle, ctypes.byref(self.struct), n, ENGINE_SEED, self.id_base, pos, wl_lo, wl_hi))
+            _lib.check(lib.chroma_generate_bomb(ctx.handle, ctypes.byref(self.struct), nphotons, ENGINE_SEED, self.id_base, pos, wl_lo, wl_hi))
+            return self
+
+    # per-step outputs, allocated once: per-channel arrays and the flat-hit buffers (get_flat_hits' destination)
+    counts = zeros(nch, np.uint32, ctx)
+    earliest = GPUArray(nch, np.uint32, ctx)
+    hit_capacity = [0]
+    hits = [None, None, None]
+
+    def ensure_hit_buffers(n):
+        if n > hit_capacity[0]:
+            cap = int(1.25 * n) + 1024
+            hits[0] = GPUPhotonsSlice(**_alloc_fields(cap, ctx))
+            hits[1] = _structure(hits[0])
+            hits[2] = empty(cap, np.int32, ctx)
+            hit_capacity[0] = cap
 
     def run_step(batch, time_kernels, stats):
         rng = _lib.Rng(ENGINE_SEED, batch.id_base)
@@ -125,20 +214,25 @@ def main():
         st = _lib.PropagateStats()
         _lib.check(lib.chroma_propagate(ctx.handle, gg.handle, ctypes.byref(batch.struct), nphotons, 1, rng,
                                         args.max_steps, 0, 0, int(time_kernels), ctypes.byref(st), ctypes.byref(aborted)))
-        counts = zeros(gg.nchannels, np.uint32, ctx)
-        earliest = GPUArray(gg.nchannels, np.uint32, ctx).fill(np.uint32(0x7f800000))
+        counts.fill(np.uint32(0))
+        earliest.fill(np.uint32(0x7f800000))
         _lib.check(lib.chroma_channel_hits(ctx.handle, gg.handle, nphotons, event.SURFACE_DETECT, ctypes.byref(batch.struct),
                                            counts.ptr, earliest.ptr))
+        # get_flat_hits (chroma/gpu/photon.py:96-175): count, then compact the detected photons + their channels
         nhits = ctypes.c_uint32()
         _lib.check(lib.chroma_count_photon_hits(ctx.handle, gg.handle, 0, nphotons, event.SURFACE_DETECT,
                                                 ctypes.byref(batch.struct), ctypes.byref(nhits)))
+        ensure_hit_buffers(nhits.value)
+        ncopied = ctypes.c_uint32()
+        _lib.check(lib.chroma_copy_photon_hits(ctx.handle, gg.handle, 0, nphotons, event.SURFACE_DETECT, ctypes.byref(batch.struct),
+                                               ctypes.byref(hits[1]), hits[2].ptr, ctypes.byref(ncopied)))
+        # the one exchange: per-channel arrays over RCCL, in place on the device (identity on one GPU)
+        _lib.check(lib.chroma_allreduce_hits(ctx.handle, counts.ptr, earliest.ptr, nch))
         c, e = counts.get(), earliest.get()
-        if world > 1:
-            from chroma_amd.dist import allreduce_channel_hits
-            c, e = allreduce_channel_hits(c, e, device=torch.device('cuda', local_rank))
         for k, v in st.as_dict().items():
             stats[k] = stats.get(k, 0) + v
         stats['hits'] = stats.get('hits', 0) + int(nhits.value)
+        stats['copied'] = stats.get('copied', 0) + int(ncopied.value)
         stats['channel_sum'] = stats.get('channel_sum', 0) + int(np.asarray(c, dtype=np.uint64).sum())
         return c, e
 
@@ -153,25 +247,35 @@ def main():
     t0 = time.time()
     count_n_stats = {}
     ctx.set_counting(True)
-    probe = Batch(10_000 + 0)
+    probe = Batch().fill(10_000)
+    ensure_hit_buffers(int(0.10 * nphotons))
     run_step(probe, False, count_n_stats)
     ctx.set_counting(False)
-    del probe
     steps_pp = count_n_stats['photon_steps'] / nphotons
     nodes_ps = count_n_stats['nodes_visited'] / max(1, count_n_stats['photon_steps'])
     tris_ps = count_n_stats['triangles_tested'] / max(1, count_n_stats['photon_steps'])
     bytes_per_step = 16.0 * nodes_ps + 48.0 * tris_ps + 40 + 120 + 8
     bytes_per_photon = bytes_per_step * steps_pp
     log('counting pass %.1f s: %.3f steps/photon, %.1f nodes/step, %.2f triangle tests/step -> %.0f B/step, %.0f B/photon; '
-        'hit fraction %.4f' % (time.time() - t0, steps_pp, nodes_ps, tris_ps, bytes_per_step, bytes_per_photon,
-                               count_n_stats['hits'] / nphotons))
+        'hit fraction %.4f; %d stack entries spilled' % (time.time() - t0, steps_pp, nodes_ps, tris_ps, bytes_per_step, bytes_per_photon,
+                                                         count_n_stats['hits'] / nphotons, count_n_stats.get('stack_spills', 0)))
+    if world > 1:
+        assert count_n_stats['channel_sum'] >= count_n_stats['hits'], 'reduced channel counts smaller than this rank\'s own'
+    else:
+        assert count_n_stats['channel_sum'] == count_n_stats['hits'] == count_n_stats['copied']
 
-    batches = [Batch(i) for i in range(nbatches)]
+    if resident:
+        buffers = [probe.fill(0)] + [Batch().fill(i) for i in range(1, nbatches)]
+    else:
+        buffers = [probe, Batch()]
     ctx.synchronize()
+
+    def batch_for(i):
+        return buffers[i] if resident else buffers[i % nbuffers].fill(i)
 
     for i in range(args.warmup):
         t_step = time.perf_counter()
-        run_step(batches[i], False, {})
+        run_step(batch_for(i), False, {})
         log('  warmup %d: %.1f ms wall' % (i, 1e3 * (time.perf_counter() - t_step)))
     sync_all()
     stats = {}
@@ -179,7 +283,7 @@ def main():
     for i in range(args.warmup, nbatches):
         t_step = time.perf_counter()
         k0 = stats.get('kernel_ms', 0.0)
-        run_step(batches[i], True, stats)
+        run_step(batch_for(i), True, stats)
         log('  step %d: %.1f ms wall, %.1f ms in propagate kernels' % (i - args.warmup, 1e3 * (time.perf_counter() - t_step), stats['kernel_ms'] - k0))
     sync_all()
     elapsed = time.perf_counter() - t_start
@@ -201,47 +305,69 @@ def main():
     ray_bytes_per_step = 16.0 * nodes_ps + 48.0 * tris_ps + 64 + 8
     ray_bytes_total = ray_bytes_per_step * steps_pp * nphotons * args.steps
     achieved = ray_bytes_total / ray_s / 1e9 if ray_s > 0 else 0.0
+    avg_launch_ms = 1e3 * ray_s / ray_launches
     log('timed: %.3f s for %d steps; propagate kernels %.3f s in %d launches, of which ray cast %.3f s in %d launches '
         '(avg %.3f ms); hits/photon %.4f' % (elapsed, args.steps, kernel_s, launches, ray_s, ray_launches,
-                                             1e3 * ray_s / ray_launches, stats['hits'] / (nphotons * args.steps)))
-    # HBM traffic of the same command from rocprofv3 PMC passes (profiles/, corrected as calibrated there)
-    traffic = None
+                                             avg_launch_ms, stats['hits'] / (nphotons * args.steps)))
+    # HBM traffic of the same command from rocprofv3 PMC passes (tools/pmc_traffic.py -> profiles/pmc_traffic.json):
+    # quoted only when that profile was taken with the kernels this run was built from
+    traffic, traffic_source, measured = None, 'none: no PMC profile of this command under profiles/', None
+    src_hash = kernel_source_hash()
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
         key = '%s:%d:%d' % (args.config, nphotons, args.max_steps)
         if key in pmc:
-            traffic = pmc[key]['hbm_bytes_per_launch']
+            rec = pmc[key]
+            if rec.get('source_hash') == src_hash:
+                traffic = rec['hbm_bytes_per_launch']
+                traffic_source = 'profiles/pmc_traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, %s, %d launches, kernels %s (= this build); %s' % (
+                    key, rec.get('date', '?'), rec.get('launches', 0), src_hash, rec.get('correction', ''))
+                measured = traffic / (avg_launch_ms * 1e-3) / 1e9
+            else:
+                traffic_source = 'stale: profiles/pmc_traffic.json[%s] was taken with kernels %s, this build is %s' % (key, rec.get('source_hash', '?'), src_hash)
     except Exception:
         pass
 
     cpu_baseline = None
-    if packed_for_cpu is not None:
+    if run_cpu:
         import oracle
-        cores = os.cpu_count() or 1
-        sample = args.cpu_sample or {'tiny': 400_000, 'lite': 1_000_000}.get(args.config, 3_000_000)
+        cores = effective_cores()
+        geo_s2c = packed.arrays['solid_id_to_channel_index']
+        geo_solid = packed.arrays['solid_id_map']
+
+        def cpu_pass(ph):
+            t0 = time.perf_counter()
+            end, _, _ = oracle.propagate(packed, ph, seed=ENGINE_SEED, photon_id_base=0, max_steps=args.max_steps, nthreads=cores)
+            det = (end.flags & event.SURFACE_DETECT) != 0
+            tri = end.last_hit_triangles
+            ok = det & (tri > -1)
+            chan = geo_s2c[geo_solid[tri[ok]]]
+            np.bincount(chan[chan >= 0], minlength=nch)
+            return time.perf_counter() - t0
+        # warm-up (also the calibration): then 3 repetitions of a sample sized for ~6 s each, 3e6..3e7 photons
+        calib = 1_000_000 if args.config in ('c3', 'detector') else 400_000
+        ph = oracle.generate_bomb(calib, seed=ENGINE_SEED, id_base=0, wavelength_lo=wl_lo, wavelength_hi=wl_hi)
+        rate0 = calib / cpu_pass(ph)
+        sample = args.cpu_sample or int(min(30_000_000, max(3_000_000 if args.config in ('c3', 'detector') else 400_000, 6.0 * rate0)))
         ph = oracle.generate_bomb(sample, seed=ENGINE_SEED, id_base=0, wavelength_lo=wl_lo, wavelength_hi=wl_hi)
-        t0 = time.perf_counter()
-        end, _, ost = oracle.propagate(packed_for_cpu, ph, seed=ENGINE_SEED, photon_id_base=0, max_steps=args.max_steps, nthreads=cores)
-        det = (end.flags & event.SURFACE_DETECT) != 0
-        tri = end.last_hit_triangles
-        ok = det & (tri > -1)
-        chan = geo.solid_id_to_channel_index[geo.solid_id[tri[ok]]]
-        np.bincount(chan[chan >= 0], minlength=gg.nchannels)
-        dt = time.perf_counter() - t0
-        cpu_baseline = {'value': sample / dt, 'unit': 'photons/s', 'cores': cores, 'kind': 'port',
-                        'sample': '%d photons of the same bomb on %s, oracle/chroma_oracle.c on %d host threads, '
-                                  'propagate + hit histogram, %.1f s wall' % (sample, args.config, cores, dt)}
-        log('cpu baseline: %.3g photons/s on %d threads' % (sample / dt, cores))
+        times = [cpu_pass(ph) for _ in range(3)]
+        rates = [sample / t for t in times]
+        cpu_baseline = {'value': float(np.mean(rates)), 'std': float(np.std(rates)), 'unit': 'photons/s', 'cores': cores,
+                        'per_thread': float(np.mean(rates)) / cores, 'kind': 'port', 'repetitions': 3,
+                        'sample': '%d photons of the same bomb on %s, oracle/chroma_oracle.c on %d host threads (of %d logical CPUs), '
+                                  'propagate + hit histogram; one warm-up pass of %d photons (%.3g/s), then 3 passes of %.1f / %.1f / %.1f s' % (
+                                      sample, args.config, cores, os.cpu_count() or 0, calib, rate0, times[0], times[1], times[2])}
+        log('cpu baseline: %.3g +- %.2g photons/s on %d threads (%.3g per thread)' % (cpu_baseline['value'], cpu_baseline['std'], cores, cpu_baseline['per_thread']))
         if args.config == 'tiny':
             # the pure-NumPy restatement, 1e4 photons, one core (numpy is single-threaded here)
             from oracle import numpy_propagate as npp
-            tab = npp.Tables(packed_for_cpu)
+            tab = npp.Tables(packed)
             ph1 = oracle.generate_bomb(10_000, seed=ENGINE_SEED, id_base=0, wavelength_lo=wl_lo, wavelength_hi=wl_hi)
-            npp.propagate(packed_for_cpu, ph1, seed=1, max_steps=args.max_steps, tables=tab)          # warm-up
+            npp.propagate(packed, ph1, seed=1, max_steps=args.max_steps, tables=tab)          # warm-up
             t0 = time.perf_counter()
             reps = 3
             for r in range(reps):
-                npp.propagate(packed_for_cpu, ph1, seed=2 + r, max_steps=args.max_steps, tables=tab)
+                npp.propagate(packed, ph1, seed=2 + r, max_steps=args.max_steps, tables=tab)
             dtn = (time.perf_counter() - t0) / reps
             cpu_baseline['numpy_c1'] = {'value': 10_000 / dtn, 'unit': 'photons/s', 'cores': 1,
                                         'sample': '1e4 photons of the same bomb, oracle/numpy_propagate.py, mean of %d runs, %.2f s each' % (reps, dtn)}
@@ -252,21 +378,29 @@ def main():
             'metric': 'photons/sec (propagate_hit)', 'value': value, 'unit': 'photons/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': value / 2.5e6 if args.config == 'c3' else None,
+            'vs_baseline': None,          # BASELINE.md holds no published number for this metric (BASELINE.json "published": {})
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': desc, 'geometry': args.config, 'triangles': int(len(geo.mesh.triangles)),
-                       'bvh_nodes': int(len(geo.bvh.nodes)), 'channels': int(geo.num_channels()),
+            'config': {'workload': desc, 'geometry': args.config, 'triangles': int(d.ntriangles),
+                       'bvh_nodes': int(d.nnodes), 'channels': int(d.nchannels),
                        'photons_per_gpu_per_step': nphotons, 'max_steps': args.max_steps,
                        'wavelength_nm': [wl_lo, wl_hi] if wl_hi > wl_lo else wl_lo,
-                       'engine_seed': ENGINE_SEED, 'parallelism': 'photon shards x%d, geometry replicated' % world,
+                       'engine_seed': ENGINE_SEED, 'parallelism': 'photon shards x%d, geometry replicated, per-channel arrays all-reduced (RCCL)' % world,
+                       'step': 'propagate(max_steps) + channel hit arrays + flat-hit count and compaction' + (' + all-reduce' if world > 1 else ''),
+                       'inputs': 'resident in HBM' if resident else 'bomb regenerated on the device inside the timed region (memory)',
+                       'target_photons_per_s_per_gpu': 2.5e6, 'vs_target': value / world / 2.5e6,
                        'steps_per_photon': steps_pp, 'nodes_per_step': nodes_ps, 'triangle_tests_per_step': tris_ps,
-                       'geometry_build_s': t_build},
+                       'geometry_build_s': t_build, 'geometry_upload_s': t_upload},
+            # achieved/frac: ALGORITHMIC bytes over the HIP-event time of the ray-cast launches (cache hits included, so
+            # this is effective bandwidth); traffic: fabric-side bytes per launch from PMC counters of this very build,
+            # hbm_measured_*: that traffic over the same launch time.  The kernel is latency-bound.
             'roofline': {'bound': 'hbm', 'kernel': RAYCAST_KERNEL, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
+                         'hbm_measured_GBps': measured, 'hbm_measured_frac': (measured / HBM_PEAK_GBS) if measured else None,
+                         'limiter': 'dependent-fetch latency at the resident wave count, not bandwidth',
                          'algorithmic_bytes_per_launch': ray_bytes_total / ray_launches,
                          'algorithmic_bytes_per_photon_step': ray_bytes_per_step,
-                         'launches': int(stats['raycast_launches']), 'avg_launch_ms': 1e3 * ray_s / ray_launches,
-                         'kernel_s': ray_s,
+                         'launches': int(stats['raycast_launches']), 'avg_launch_ms': avg_launch_ms,
+                         'kernel_s': ray_s, 'kernel_source_hash': src_hash,
                          'path': {'achieved': path_achieved, 'frac': path_achieved / HBM_PEAK_GBS,
                                   'algorithmic_bytes_per_photon': bytes_per_photon, 'launches': int(stats['launches']),
                                   'kernel_s': kernel_s}},

@@ -49,6 +49,8 @@ class GeometryDesc(Structure):
         ('dichroic_angles', c_void_p), ('dichroic_reflect', c_void_p), ('dichroic_transmit', c_void_p),
         ('solid_id_to_channel_index', c_void_p),
         ('nsolids', c_uint32), ('nchannels', c_uint32),
+        ('wide_nodes', c_void_p), ('wide_tri_to_record', c_void_p), ('wide_record_to_tri', c_void_p),
+        ('wide_rank', c_void_p), ('nwide', c_uint64), ('nrecords', c_uint64),
     ]
 
 
@@ -127,6 +129,11 @@ SIGNATURES = {
     'chroma_daq_convert': (c_int32, [c_void_p, c_uint32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'chroma_generate_bomb': (c_int32, [c_void_p, POINTER(PhotonArrays), c_uint64, c_uint64, c_uint64,
                                        POINTER(c_float), c_float, c_float]),
+    'chroma_comm_unique_id': (c_int32, [c_void_p]),
+    'chroma_comm_init': (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
+    'chroma_comm_destroy': (c_int32, [c_void_p]),
+    'chroma_allreduce_hits': (c_int32, [c_void_p, c_void_p, c_void_p, c_uint32]),
+    'chroma_allreduce_daq': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
     'chroma_probe': (c_int32, [c_void_p, c_int32, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32, c_float, c_float, c_void_p]),
     'chroma_bvh_build': (c_int32, [c_void_p, c_uint32, c_void_p, c_uint32, POINTER(c_float), c_float, c_int32,
                                    POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint32)]),

@@ -15,6 +15,9 @@
 #include <chrono>
 #include <atomic>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and prototypes only: RCCL itself is found with dlopen at first use
+
 #include "propagate_device.h"
 #include "wide_build.h"
 #include "host_utils.h"
@@ -84,6 +87,11 @@ struct chroma_ctx {
     int split_tail = 1;                    // 0 (CHROMA_TAIL=fused): chroma_propagate launches the fused kernel only, as the reference does
     int wide_walk = CHROMA_WALK_QUAD;      // CHROMA_WALK_*: reference tree | wide tree with 1, 8 or 4 (default) lanes per ray
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
+    // the one exchange of the path (per-channel hit arrays): an RCCL communicator over the node's GPUs
+    ncclComm_t comm = nullptr;
+    int comm_nranks = 1, comm_rank = 0;
+    uint32_t *gather_buf = nullptr;        // [comm_nranks][n] words for the OR reduction (all-gather + local OR)
+    size_t gather_capacity = 0;
 };
 
 struct chroma_geometry {
@@ -2317,6 +2325,7 @@ int chroma_shutdown(chroma_ctx *ctx)
     if (!ctx) return CHROMA_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    chroma_comm_destroy(ctx);
     if (ctx->queue_a) hipFree(ctx->queue_a);
     if (ctx->queue_b) hipFree(ctx->queue_b);
     if (ctx->wide_spill) hipFree(ctx->wide_spill);
@@ -2501,30 +2510,41 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     { const uint4 *p; if ((rc = upload(g, (const uint4 *)d->nodes, d->nnodes, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_nodes_api = (void *)p; }
     // derived 8-wide tree, device triangle order and reference test ranks (csrc/wide_build.cpp)
     chroma_host::WideTree wt;
-    {
+    const bool wide_given = d->wide_nodes != nullptr;
+    if (wide_given) {
+        if (!d->wide_tri_to_record || !d->wide_record_to_tri || !d->wide_rank || d->nwide == 0 || d->nrecords == 0) {
+            chroma_geometry_destroy(g);
+            return set_error(CHROMA_ERR_INVALID, "geometry: a supplied wide tree needs its nodes, both record maps and the ranks");
+        }
+    } else {
         std::string werr;
         if (chroma_host::build_wide_tree(d->nodes, d->nnodes, d->ntriangles, wt, werr, chroma_host::wide_topology_from_env()) != 0) {
             chroma_geometry_destroy(g);
             return set_error(CHROMA_ERR_INVALID, "%s", werr.c_str());
         }
     }
-    phase("nodes upload + wide tree");
-    const std::vector<uint32_t> &tri_to_dev = wt.tri_to_dev, &dev_to_tri = wt.dev_to_tri;
-    const size_t nrecords = dev_to_tri.size();
+    phase(wide_given ? "nodes upload" : "nodes upload + wide tree");
+    const uint32_t *wide_nodes = wide_given ? d->wide_nodes : wt.wnodes.data();
+    const uint32_t *tri_to_dev = wide_given ? d->wide_tri_to_record : wt.tri_to_dev.data();
+    const uint32_t *dev_to_tri = wide_given ? d->wide_record_to_tri : wt.dev_to_tri.data();
+    const uint32_t *tri_rank = wide_given ? d->wide_rank : wt.rank.data();
+    const size_t nwide = wide_given ? (size_t)d->nwide : wt.nwide;
+    const size_t nrecords = wide_given ? (size_t)d->nrecords : wt.dev_to_tri.size();
     {   // the walks index the wide nodes and the records with what this tree holds: check it before any upload
         std::string werr;
-        if (chroma_host::validate_wide_tree(wt.wnodes.data(), wt.nwide, tri_to_dev.data(), d->ntriangles, dev_to_tri.data(), nrecords, werr) != 0) {
+        if (chroma_host::validate_wide_tree(wide_nodes, nwide, tri_to_dev, d->ntriangles, dev_to_tri, nrecords, werr) != 0) {
             chroma_geometry_destroy(g);
             return set_error(CHROMA_ERR_INVALID, "%s", werr.c_str());
         }
     }
     phase("wide tree index checks");
-    { const uint4 *p; if ((rc = upload(g, (const uint4 *)wt.wnodes.data(), wt.nwide * 8, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } v.wnodes = p; }
-    v.nwide = (uint32_t)wt.nwide;
-    g->nwide = wt.nwide; g->wide_depth = wt.depth; g->nrecords = nrecords; g->wide_stack_need = wt.stack_need;
+    { const uint4 *p; if ((rc = upload(g, (const uint4 *)wide_nodes, nwide * 8, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } v.wnodes = p; }
+    v.nwide = (uint32_t)nwide;
+    g->nwide = nwide; g->wide_depth = wt.depth; g->nrecords = nrecords;
+    g->wide_stack_need = wide_given ? chroma_host::wide_stack_need(wide_nodes, nwide) : wt.stack_need;
     { std::vector<uint32_t>().swap(wt.wnodes); }
-    UP(tri_to_dev, tri_to_dev.data(), tri_to_dev.size());
-    UP(dev_to_tri, dev_to_tri.data(), dev_to_tri.size());
+    UP(tri_to_dev, tri_to_dev, d->ntriangles);
+    UP(dev_to_tri, dev_to_tri, nrecords);
     // traversal copy of the nodes: leaf child -> device triangle index
     {
         void *dn = nullptr;
@@ -2570,7 +2590,7 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
                         const float *vv = d->vertices + 3 * (size_t)d->triangles[3 * t + c];
                         r[4 * c] = vv[0]; r[4 * c + 1] = vv[1]; r[4 * c + 2] = vv[2];
                     }
-                    uint32_t code = d->material_codes[t], tid = (uint32_t)t, rank = wt.rank[t];
+                    uint32_t code = d->material_codes[t], tid = (uint32_t)t, rank = tri_rank[t];
                     memcpy(&r[3], &code, 4); memcpy(&r[7], &tid, 4); memcpy(&r[11], &rank, 4);
                 }
             });
@@ -3184,6 +3204,142 @@ int chroma_generate_bomb(chroma_ctx *ctx, const chroma_photon_arrays *photons, u
     if (nphotons == 0) return CHROMA_OK;
     hipLaunchKernelGGL(k_generate_bomb, dim3((unsigned)((nphotons + 255) / 256)), dim3(256), 0, ctx->stream, to_view(photons),
                        (uint64_t)nphotons, seed, id_base, pos[0], pos[1], pos[2], wavelength_lo, wavelength_hi);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+// ---- the hit reduction across GPUs ----------------------------------------------------
+// Photons never interact and every GPU holds the whole geometry, so a batch sharded over the GPUs of a
+// node needs exactly one exchange: its per-channel arrays.  That exchange is RCCL on the library's own
+// stream, on the device arrays the hit kernels filled -- nothing is staged through the host.  RCCL is
+// found with dlopen when the first communicator call is made (a process that already holds an RCCL, e.g.
+// torch's, gets that one through the shared-object name), so single-GPU users never load it.
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_load()
+{
+    if (g_rccl.handle) return CHROMA_OK;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return set_error(CHROMA_ERR_INVALID, "RCCL not found (dlopen librccl.so.1): %s", dlerror());
+#define SYM(field, name) \
+    do { *(void **)(&g_rccl.field) = dlsym(h, name); \
+         if (!g_rccl.field) { dlclose(h); return set_error(CHROMA_ERR_INVALID, "RCCL: symbol %s missing", name); } } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather"); SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.handle = h;
+    return CHROMA_OK;
+}
+#define RCCL_TRY(expr)                                                                             \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess)                                                                     \
+            return set_error(CHROMA_ERR_INVALID, "%s failed: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+__global__ void k_or_gathered(uint32_t *out, const uint32_t *gathered, uint32_t n, int nranks)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t acc = 0;
+    for (int r = 0; r < nranks; r++) acc |= gathered[(size_t)r * n + i];
+    out[i] = acc;
+}
+
+int chroma_comm_unique_id(uint8_t id[CHROMA_COMM_ID_BYTES])
+{
+    if (!id) return set_error(CHROMA_ERR_INVALID, "null id");
+    static_assert(CHROMA_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    int rc = rccl_load(); if (rc) return rc;
+    ncclUniqueId u;
+    RCCL_TRY(g_rccl.GetUniqueId(&u));
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return CHROMA_OK;
+}
+
+int chroma_comm_init(chroma_ctx *ctx, int32_t nranks, int32_t rank, const uint8_t id[CHROMA_COMM_ID_BYTES])
+{
+    if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (ctx->comm) return set_error(CHROMA_ERR_INVALID, "this context already has a communicator");
+    int rc = rccl_load(); if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    RCCL_TRY(g_rccl.CommInitRank(&ctx->comm, nranks, u, rank));
+    ctx->comm_nranks = nranks;
+    ctx->comm_rank = rank;
+    return CHROMA_OK;
+}
+
+int chroma_comm_destroy(chroma_ctx *ctx)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    if (ctx->comm) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        RCCL_TRY(g_rccl.CommDestroy(ctx->comm));
+        ctx->comm = nullptr;
+        ctx->comm_nranks = 1;
+        ctx->comm_rank = 0;
+    }
+    if (ctx->gather_buf) { hipFree(ctx->gather_buf); ctx->gather_buf = nullptr; ctx->gather_capacity = 0; }
+    return CHROMA_OK;
+}
+
+// hit_count: sum; earliest-time bit patterns: min (non-negative times order like their bits,
+// chroma/cuda/daq.cu:5-20).  In place, on the library's stream; without a communicator the arrays
+// already are the whole job's.
+int chroma_allreduce_hits(chroma_ctx *ctx, uint32_t *d_hit_count, uint32_t *d_earliest_time_bits, uint32_t nchannels)
+{
+    if (!ctx || !d_hit_count) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (!ctx->comm || nchannels == 0) return CHROMA_OK;
+    RCCL_TRY(g_rccl.GroupStart());
+    RCCL_TRY(g_rccl.AllReduce(d_hit_count, d_hit_count, nchannels, ncclUint32, ncclSum, ctx->comm, ctx->stream));
+    if (d_earliest_time_bits)
+        RCCL_TRY(g_rccl.AllReduce(d_earliest_time_bits, d_earliest_time_bits, nchannels, ncclUint32, ncclMin, ctx->comm, ctx->stream));
+    RCCL_TRY(g_rccl.GroupEnd());
+    return CHROMA_OK;
+}
+
+// The three integer arrays a DAQ acquisition accumulates (chroma/cuda/daq.cu:73-75) over sharded photons:
+// earliest time bits (min), integer charge (sum), channel histories (bitwise OR -- not an RCCL reduction:
+// all-gather, then OR locally).
+int chroma_allreduce_daq(chroma_ctx *ctx, uint32_t *d_earliest_time_int, uint32_t *d_channel_q_int,
+                         uint32_t *d_channel_histories, uint32_t nchannels)
+{
+    if (!ctx || !d_earliest_time_int || !d_channel_q_int || !d_channel_histories) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (!ctx->comm || nchannels == 0) return CHROMA_OK;
+    const size_t need = (size_t)ctx->comm_nranks * nchannels;
+    if (ctx->gather_capacity < need) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->gather_buf) hipFree(ctx->gather_buf);
+        ctx->gather_buf = nullptr; ctx->gather_capacity = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->gather_buf, need * sizeof(uint32_t)));
+        ctx->gather_capacity = need;
+    }
+    RCCL_TRY(g_rccl.GroupStart());
+    RCCL_TRY(g_rccl.AllReduce(d_earliest_time_int, d_earliest_time_int, nchannels, ncclUint32, ncclMin, ctx->comm, ctx->stream));
+    RCCL_TRY(g_rccl.AllReduce(d_channel_q_int, d_channel_q_int, nchannels, ncclUint32, ncclSum, ctx->comm, ctx->stream));
+    RCCL_TRY(g_rccl.AllGather(d_channel_histories, ctx->gather_buf, nchannels, ncclUint32, ctx->comm, ctx->stream));
+    RCCL_TRY(g_rccl.GroupEnd());
+    hipLaunchKernelGGL(k_or_gathered, dim3((nchannels + 255) / 256), dim3(256), 0, ctx->stream, d_channel_histories,
+                       ctx->gather_buf, nchannels, ctx->comm_nranks);
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
 }

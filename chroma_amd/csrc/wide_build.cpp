@@ -606,21 +606,7 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
     phase("topology");
     // worst case of the walk's stack: at a node, every inner child but the one walked next is
     // pushed, then the same below -- whichever child is walked, so the maximum over children
-    {
-        std::vector<uint16_t> need(out.nwide, 0);
-        for (size_t i = out.nwide; i-- > 0;) {
-            const uint32_t *wn = out.wnodes.data() + i * 32;
-            uint32_t inner = 0, below = 0;
-            for (int j = 0; j < WIDE_K; j++) {
-                uint32_t w = wn[4 * j + 3];
-                if (w == WIDE_EMPTY || (w & WIDE_LEAF)) continue;
-                inner++;
-                below = std::max<uint32_t>(below, need[w]);
-            }
-            need[i] = (uint16_t)std::min<uint32_t>(0xFFFF, inner ? inner - 1 + below : 0);
-        }
-        out.stack_need = out.nwide ? need[0] : 0;
-    }
+    out.stack_need = wide_stack_need(out.wnodes.data(), out.nwide);
     // device index of every triangle (a triangle under several leaves keeps the first; triangles
     // under no leaf go to the end so that every triangle has a record)
     for (size_t d = 0; d < out.dev_to_tri.size(); d++) {
@@ -631,6 +617,23 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
         if (out.tri_to_dev[t] == 0xFFFFFFFFu) { out.tri_to_dev[t] = (uint32_t)out.dev_to_tri.size(); out.dev_to_tri.push_back(t); }
     phase("stack need + record map");
     return 0;
+}
+
+uint32_t wide_stack_need(const uint32_t *wnodes, size_t nwide)
+{
+    std::vector<uint16_t> need(nwide, 0);
+    for (size_t i = nwide; i-- > 0;) {
+        const uint32_t *wn = wnodes + i * 32;
+        uint32_t inner = 0, below = 0;
+        for (int j = 0; j < (int)WIDE_K; j++) {
+            uint32_t w = wn[4 * j + 3];
+            if (w == WIDE_EMPTY || (w & WIDE_LEAF)) continue;
+            inner++;
+            if ((size_t)w < nwide && (size_t)w > i) below = std::max<uint32_t>(below, need[w]);
+        }
+        need[i] = (uint16_t)std::min<uint32_t>(0xFFFF, inner ? inner - 1 + below : 0);
+    }
+    return nwide ? need[0] : 0;
 }
 
 // What the device walks index with, checked before anything is uploaded: every inner child word names a

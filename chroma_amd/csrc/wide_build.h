@@ -26,6 +26,8 @@ struct WideTree {
 // stored after every node of their parent's layer).  Returns 0, or -1 with `err` set.
 int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, WideTree &out, std::string &err,
                     int topology = WIDE_TOPOLOGY_SAH);
+// most entries the nearest-first walk over this tree can hold at once (children follow their parents)
+uint32_t wide_stack_need(const uint32_t *wnodes, size_t nwide);
 // Index checks of a wide tree and its record maps (see wide_build.cpp).  Returns 0, or -1 with `err` set.
 int validate_wide_tree(const uint32_t *wnodes, size_t nwide, const uint32_t *tri_to_dev, uint32_t ntriangles,
                        const uint32_t *dev_to_tri, size_t nrecords, std::string &err);

@@ -60,3 +60,69 @@ def allreduce_daq_channels(earliest_time_bits, charge_int, histories, device=Non
             hist = torch.bitwise_or(hist, part)
     return (times.cpu().numpy().astype(np.uint32), (charge.cpu().numpy() & 0xFFFFFFFF).astype(np.uint32),
             hist.cpu().numpy().astype(np.uint32))
+
+
+# ---- the reduction inside the library: RCCL on device arrays --------------------------------------------
+def init_comm(ctx, rank=None, world_size=None):
+    """Give ``ctx`` (a chroma_amd.gpu context) an RCCL communicator over the ranks of the default
+    torch.distributed process group: rank 0 asks the library for an id (chroma_comm_unique_id) and
+    torch.distributed carries its 128 bytes to the others -- rendezvous is all torch does here; the
+    reductions themselves (chroma_allreduce_hits / chroma_allreduce_daq) run inside the library on the
+    device arrays, with no copy through the host.  Without a process group (one GPU) nothing happens."""
+    import ctypes
+    import torch.distributed as dist
+    from chroma_amd import _lib
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    rank = dist.get_rank() if rank is None else rank
+    world_size = dist.get_world_size() if world_size is None else world_size
+    ident = (ctypes.c_uint8 * 128)()
+    if rank == 0:
+        _lib.check(ctx._lib.chroma_comm_unique_id(ident))
+    box = [bytes(ident)]
+    dist.broadcast_object_list(box, src=0)
+    ident = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+    _lib.check(ctx._lib.chroma_comm_init(ctx.handle, int(world_size), int(rank), ident))
+    return True
+
+
+def allreduce_channel_hits_device(ctx, counts, earliest):
+    """In-place all-reduce of the per-channel device arrays GPUPhotons.channel_hits returned
+    (``counts``: sum, ``earliest``: min of non-negative float bit patterns) over the context's
+    communicator (init_comm).  The identity on a context without one."""
+    from chroma_amd import _lib
+    _lib.check(ctx._lib.chroma_allreduce_hits(ctx.handle, counts.ptr, None if earliest is None else earliest.ptr, len(counts)))
+    return counts, earliest
+
+
+def publish_packed_geometry(build, key, local_rank, barrier, shm_dir='/dev/shm'):
+    """One geometry per NODE instead of one per process.  The process with ``local_rank`` 0 calls
+    ``build()`` -> PackedGeometry (mesh, BVH, optics tables and the derived wide tree: the 30 s of
+    all-core work of a 170 M-triangle detector), saves it under ``shm_dir`` as plain .npy files and
+    passes ``barrier()``; the other processes pass the barrier and memory-map the same files, so the
+    ~16 GB of host arrays exist once per node.  Returns (packed, directory); the caller removes the
+    directory (remove_published) after every rank has uploaded."""
+    import os
+    from chroma_amd.gpu.geometry import PackedGeometry
+    path = os.path.join(shm_dir, 'chroma_amd_%s_%d' % (key, os.getuid()))
+    if local_rank == 0:
+        import shutil
+        shutil.rmtree(path, ignore_errors=True)
+        packed = build()
+        if 'wide_nodes' not in packed.arrays:
+            packed.attach_wide_tree()
+        packed.save(path)
+        barrier()
+        return packed, path
+    barrier()
+    return PackedGeometry.load(path, mmap=True), path
+
+
+def remove_published(path, local_rank, barrier):
+    """After every rank has uploaded (first barrier) local rank 0 deletes the files; nobody returns before
+    they are gone (second barrier)."""
+    import shutil
+    barrier()
+    if local_rank == 0:
+        shutil.rmtree(path, ignore_errors=True)
+    barrier()

@@ -43,6 +43,57 @@ class PackedGeometry(object):
         setattr(self.desc, name, a.ctypes.data if a.size else None)
         return a
 
+    def attach_wide_tree(self, wide=None):
+        """Carry the derived 8-wide traversal tree along (``wide``: what chroma_amd._lib.wide_build returned
+        for these nodes; None: build it now), so that chroma_geometry_create uploads it instead of deriving
+        it again -- once per cache file, or once per node when several processes drive one GPU each."""
+        if wide is None:
+            wide = _lib.wide_build(self.arrays['nodes'], self.desc.ntriangles)
+        self.put('wide_nodes', wide['wnodes'], np.uint32)
+        self.put('wide_tri_to_record', wide['tri_to_record'], np.uint32)
+        self.put('wide_record_to_tri', wide['record_to_tri'], np.uint32)
+        self.put('wide_rank', wide['rank'], np.uint32)
+        self.desc.nwide = self.arrays['wide_nodes'].size // 32
+        self.desc.nrecords = len(self.arrays['wide_record_to_tri'])
+        return self
+
+    # ---- as a directory of .npy files (memory-mapped on load: processes of one node share the pages) ----
+    def save(self, path):
+        import json
+        import os
+        os.makedirs(path, exist_ok=True)
+        scalars = {}
+        for name, ctype in self.desc._fields_:
+            if ctype is ctypes.c_void_p:
+                continue
+            v = getattr(self.desc, name)
+            scalars[name] = [float(x) for x in v] if hasattr(v, '__len__') else v
+        for name, a in self.arrays.items():
+            np.save(os.path.join(path, name + '.npy'), a)
+        with open(os.path.join(path, 'desc.json.tmp'), 'w') as f:
+            json.dump({'scalars': scalars, 'arrays': sorted(self.arrays)}, f)
+        os.replace(os.path.join(path, 'desc.json.tmp'), os.path.join(path, 'desc.json'))      # (the last file written)
+        return path
+
+    @classmethod
+    def load(cls, path, mmap=True):
+        import json
+        import os
+        with open(os.path.join(path, 'desc.json')) as f:
+            meta = json.load(f)
+        pk = cls()
+        for name, v in meta['scalars'].items():
+            if isinstance(v, list):
+                for k, x in enumerate(v):
+                    getattr(pk.desc, name)[k] = x
+            else:
+                setattr(pk.desc, name, v)
+        for name in meta['arrays']:
+            a = np.load(os.path.join(path, name + '.npy'), mmap_mode='r' if mmap else None)
+            pk.arrays[name] = a
+            setattr(pk.desc, name, a.ctypes.data if a.size else None)
+        return pk
+
 
 def pack_geometry(geometry, wavelengths=None, times=None):
     """Everything chroma_geometry_create needs, as host arrays.  ``geometry`` must be
@@ -200,6 +251,33 @@ class GPUGeometry(object):
         if print_usage:
             self.print_device_usage()
         logger.info(self.device_usage_str())
+
+    @classmethod
+    def from_packed(cls, packed):
+        """Upload a PackedGeometry without the Geometry object it was made from (a rank that loaded the
+        arrays another process of its node packed): everything the propagate / hit path needs."""
+        self = cls.__new__(cls)
+        self.ctx = get_context()
+        self.packed = packed
+        handle = ctypes.c_void_p()
+        _lib.check(self.ctx._lib.chroma_geometry_create(self.ctx.handle, ctypes.byref(packed.desc), ctypes.byref(handle)))
+        self.handle = handle
+        self.gpudata = handle
+        self.geometry = None
+        self.world_origin = vec.make_float3(*[packed.desc.world_origin[k] for k in range(3)])
+        self.world_scale = np.float32(packed.desc.world_scale)
+        self.vertices = self._device_array('vertices', vec.float3)
+        self.triangles = self._device_array('triangles', vec.uint3)
+        self.nodes = self._device_array('nodes', vec.uint4)
+        self.extra_nodes = GPUArray.from_pointer(self.nodes.ptr, 0, vec.uint4, self, ctx=self.ctx)
+        self.material_codes = self._device_array('material_codes', np.uint32)
+        self.colors = self._device_array('colors', np.uint32)
+        self.solid_id_map = self._device_array('solid_id_map', np.uint32)
+        if packed.desc.nsolids:
+            self.solid_id_to_channel_index_gpu = self._device_array('solid_id_to_channel_index', np.int32)
+        self.nchannels = int(packed.desc.nchannels)
+        self.detector_gpu = handle
+        return self
 
     def _device_array(self, name, dtype):
         p, nbytes = ctypes.c_void_p(), ctypes.c_size_t()

@@ -121,6 +121,15 @@ typedef struct chroma_geometry_desc {
     /* detector part (chroma/gpu/detector.py:17-40); nsolids == 0 for a plain Geometry */
     const int32_t  *solid_id_to_channel_index; /* [nsolids] */
     uint32_t nsolids, nchannels;
+    /* OPTIONAL: the derived traversal tree of `nodes`, as chroma_wide_build returned it for exactly
+     * these nodes (a cache, or one process of a node building it for the others).  wide_nodes == NULL:
+     * chroma_geometry_create derives it (16 s of all-core work at 170 M triangles).  A supplied tree goes
+     * through the same index checks (chroma_wide_validate) before anything is uploaded. */
+    const uint32_t *wide_nodes;             /* [nwide][8][4] */
+    const uint32_t *wide_tri_to_record;     /* [ntriangles]  */
+    const uint32_t *wide_record_to_tri;     /* [nrecords]    */
+    const uint32_t *wide_rank;              /* [ntriangles]  */
+    uint64_t nwide, nrecords;
 } chroma_geometry_desc;
 
 /* The nine photon arrays of chroma/cuda/propagate.cu:220-225 plus the per-photon
@@ -302,6 +311,23 @@ int chroma_daq_convert(chroma_ctx *ctx, uint32_t nchannels, float charge_unit, c
 int chroma_generate_bomb(chroma_ctx *ctx, const chroma_photon_arrays *photons, uint64_t nphotons,
                          uint64_t seed, uint64_t id_base, const float pos[3],
                          float wavelength_lo, float wavelength_hi);
+
+/* ---- the hit reduction across the GPUs of a node ------------------------------
+ * The reference has no multi-GPU mode.  Here one process drives one GPU, photons are sharded by
+ * global id, the geometry is replicated, and the ONE exchange per batch is the per-channel arrays:
+ * RCCL over xGMI, on the library's stream, in place on the device arrays chroma_channel_hits /
+ * chroma_daq_acquire filled.  Rendezvous: one rank calls chroma_comm_unique_id and hands the 128
+ * bytes to the others by any means (bench.py: torch.distributed broadcast); every rank then calls
+ * chroma_comm_init.  Without a communicator the reductions are the identity (single GPU). */
+#define CHROMA_COMM_ID_BYTES 128
+int chroma_comm_unique_id(uint8_t id[CHROMA_COMM_ID_BYTES]);
+int chroma_comm_init(chroma_ctx *ctx, int32_t nranks, int32_t rank, const uint8_t id[CHROMA_COMM_ID_BYTES]);
+int chroma_comm_destroy(chroma_ctx *ctx);
+/* hit_count: sum; earliest-time bit patterns: min (valid for t >= 0, chroma/cuda/daq.cu:5-20); d_earliest may be NULL */
+int chroma_allreduce_hits(chroma_ctx *ctx, uint32_t *d_hit_count, uint32_t *d_earliest_time_bits, uint32_t nchannels);
+/* DAQ accumulators of sharded photons (chroma/cuda/daq.cu:73-75): time bits min, integer charge sum, histories OR */
+int chroma_allreduce_daq(chroma_ctx *ctx, uint32_t *d_earliest_time_int, uint32_t *d_channel_q_int,
+                         uint32_t *d_channel_histories, uint32_t nchannels);
 
 /* Test probe: ONE call per element of a single device function of the propagate path, so that tests
  * can pin the engine's own device code on the CPU oracle and on the reference's headers compiled for

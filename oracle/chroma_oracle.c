@@ -935,16 +935,28 @@ static void propagate_one(Geo *g, const chroma_photon_arrays *a, size_t photon_i
     a->evidx[photon_id] = p.evidx;
 }
 
+/* A launch is shared by the host threads in blocks of JOB_BLOCK queue entries taken from one atomic
+ * cursor (photons differ a lot in length, so equal static shares leave threads idle); every thread counts
+ * in a Counters of its OWN on its stack -- the Job structs are adjacent in memory, and counters bumped per
+ * node visit inside them made 256 threads fight over cache lines -- and adds it to its Job once, at the end. */
+#define JOB_BLOCK 1024
 typedef struct {
-    Geo *g; const chroma_photon_arrays *a; const uint32_t *ids; size_t begin, end; chroma_rng rng;
+    Geo *g; const chroma_photon_arrays *a; const uint32_t *ids; size_t n; size_t *cursor; chroma_rng rng;
     int max_steps, use_weights, scatter_first; Counters cnt;
 } Job;
 
 static void *job_main(void *arg)
 {
     Job *j = (Job *)arg;
-    for (size_t i = j->begin; i < j->end; i++)
-        propagate_one(j->g, j->a, j->ids[i], j->rng, j->max_steps, j->use_weights, j->scatter_first, &j->cnt);
+    Counters cnt; memset(&cnt, 0, sizeof cnt);
+    for (;;) {
+        size_t begin = __atomic_fetch_add(j->cursor, (size_t)JOB_BLOCK, __ATOMIC_RELAXED);
+        if (begin >= j->n) break;
+        size_t end = begin + JOB_BLOCK < j->n ? begin + JOB_BLOCK : j->n;
+        for (size_t i = begin; i < end; i++)
+            propagate_one(j->g, j->a, j->ids[i], j->rng, j->max_steps, j->use_weights, j->scatter_first, &cnt);
+    }
+    j->cnt = cnt;
     return NULL;
 }
 
@@ -972,15 +984,12 @@ int oracle_propagate(const chroma_geometry_desc *g, const chroma_photon_arrays *
     while (step < max_steps) {
         int nsteps = (n < finish_threshold || use_weights) ? (max_steps - step) : 1;
         int nt = nthreads;
-        if ((uint64_t)nt > n) nt = (int)n;
-        size_t chunk = (size_t)((n + (uint64_t)nt - 1) / (uint64_t)nt);
+        if ((uint64_t)nt > (n + JOB_BLOCK - 1) / JOB_BLOCK) nt = (int)((n + JOB_BLOCK - 1) / JOB_BLOCK);
+        size_t cursor = 0;
         for (int i = 0; i < nt; i++) {
             memset(&jobs[i], 0, sizeof(Job));
             jobs[i].g = g; jobs[i].a = a; jobs[i].ids = alive; jobs[i].rng = rng;
-            jobs[i].begin = (size_t)i * chunk;
-            jobs[i].end = jobs[i].begin + chunk;
-            if (jobs[i].begin > n) jobs[i].begin = (size_t)n;
-            if (jobs[i].end > n) jobs[i].end = (size_t)n;
+            jobs[i].n = (size_t)n; jobs[i].cursor = &cursor;
             jobs[i].max_steps = nsteps; jobs[i].use_weights = use_weights; jobs[i].scatter_first = scatter_first;
         }
         if (nt == 1) {

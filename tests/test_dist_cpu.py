@@ -1,6 +1,8 @@
-"""The N > 1 path on the CPU: two ranks over gloo, each propagating its photon shard with the
-oracle (standing in for its GPU) and all-reducing the per-channel hit arrays with
-chroma_amd.dist -- the code bench.py runs over RCCL.  Because a photon's Philox stream is keyed
+"""The N > 1 path on the CPU: two and four ranks over gloo, sharing ONE geometry published by local
+rank 0 under /dev/shm (chroma_amd.dist.publish_packed_geometry, as bench.py --gpus N does), each
+propagating its photon shard with the oracle (standing in for its GPU) and all-reducing the per-channel
+hit arrays with chroma_amd.dist (on the GPUs the same reduction runs inside the library over RCCL:
+chroma_allreduce_hits, exercised with a one-rank communicator in tests/test_gpu_comm.py).  Because a photon's Philox stream is keyed
 by its GLOBAL id, the reduced result must equal the single-process result bit for bit."""
 import os
 import socket
@@ -48,12 +50,29 @@ def _worker(rank, world, port, nphotons, outdir):
     from chroma_amd.loader import create_geometry_from_obj
     from chroma_amd.gpu.geometry import pack_geometry
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    geo = create_geometry_from_obj(demo.tiny())
-    pk = pack_geometry(geo)
+    # the geometry of a node is built ONCE (local rank 0: mesh, BVH, packed tables, derived wide tree) and
+    # published under /dev/shm; the other ranks map the same files (what bench.py --gpus N does)
+    from chroma_amd.dist import publish_packed_geometry, remove_published
+    built = []
+
+    def build():
+        built.append(rank)
+        return pack_geometry(create_geometry_from_obj(demo.tiny()))
+    pk, shm = publish_packed_geometry(build, 'test_%d' % port, rank, dist.barrier)
+    assert built == ([0] if rank == 0 else [])
+    assert pk.desc.nwide > 0 and 'wide_nodes' in pk.arrays
+    if rank != 0:
+        assert isinstance(pk.arrays['nodes'], np.memmap)
+    geo = create_geometry_from_obj(demo.tiny()) if rank == 0 else None
+    solid_id, s2c, nchannels = pk.arrays['solid_id_map'], pk.arrays['solid_id_to_channel_index'], int(pk.desc.nchannels)
     lo, hi = shard_range(nphotons, rank, world)
     photons = oracle.generate_bomb(hi - lo, seed=12345, id_base=lo)          # the shard's own photons
     end, _, _ = oracle.propagate(pk, photons, seed=12345, photon_id_base=lo, max_steps=100)
-    counts, earliest = _channel_arrays(geo, end, geo.num_channels())
+    from types import SimpleNamespace
+    _Maps = SimpleNamespace(solid_id_to_channel_index=s2c, solid_id=solid_id)      # (what _channel_arrays reads of a Detector)
+    if rank == 0:
+        assert np.array_equal(geo.solid_id, solid_id) and geo.num_channels() == nchannels
+    counts, earliest = _channel_arrays(_Maps, end, nchannels)
     counts, earliest = allreduce_channel_hits(counts, earliest)
     # a DAQ acquisition over the shard (global photon ids again), reduced the same way
     from chroma_amd.dist import allreduce_daq_channels
@@ -62,7 +81,8 @@ def _worker(rank, world, port, nphotons, outdir):
     daq_t, daq_q, daq_h = allreduce_daq_channels(t.view(np.uint32), q_int, hist)
     if rank == 0:
         np.savez(os.path.join(outdir, 'reduced.npz'), counts=counts, earliest=earliest, daq_t=daq_t, daq_q=daq_q, daq_h=daq_h)
-    dist.barrier()
+    remove_published(shm, rank, dist.barrier)
+    assert not os.path.exists(shm)
     dist.destroy_process_group()
 
 
@@ -77,11 +97,12 @@ def test_shard_range_partitions_exactly():
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_hit_reduction_equals_single_process(tmp_path, oracle_mod, tiny_geometry, tiny_packed):
+@pytest.mark.parametrize('world', [2, 4])
+def test_sharded_hit_reduction_equals_single_process(tmp_path, oracle_mod, tiny_geometry, tiny_packed, world):
     torch = pytest.importorskip('torch')
     import torch.multiprocessing as mp
     nphotons = 30000
-    mp.spawn(_worker, args=(2, _free_port(), nphotons, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), nphotons, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / 'reduced.npz')
     photons = oracle_mod.generate_bomb(nphotons, seed=12345, id_base=0)
     end, _, _ = oracle_mod.propagate(tiny_packed, photons, seed=12345, photon_id_base=0, max_steps=100, nthreads=4)
