@@ -81,6 +81,7 @@ struct chroma_ctx {
     uint2 *wide_spill = nullptr;           // [wide_waves][WIDE_SPILL][64] stack entries beyond the LDS part
     int coop_waves = 256 * 32;             // grid of k_raycast_coop (2 KB of LDS per wave: wave slots limit residency)
     int quad_waves = 256 * 24;             // grid of k_raycast_quad
+    int pair_waves = 256 * 20;             // grid of k_raycast_pair (32 rays per wave)
     uint2 *coop_spill = nullptr;           // [coop_waves][8][COOP_SPILL]
     int ray_chunk = 256, coop_chunk = 64;  // rays a persistent wave takes from the queue per atomic (big batches)
     int fused_tail = 1;                    // 0 (CHROMA_TAIL=split): the last photons also take one launch set per step
@@ -1193,6 +1194,280 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     }
 }
 
+
+// ---- the same ray cast with TWO lanes per ray, four child entries per lane -----------------------------
+// 32 rays per wavefront.  The ray cast is bound by instruction issue plus the latency of a wave's chain
+// per node visit, and the four-lane kernel pays its per-visit bookkeeping (the quad-wide word, prefix
+// counts, the reduction that picks the nearest child, pop and loop control: two thirds of a visit's
+// instructions) once per 16 rays.  Here the same bookkeeping serves 32 rays: a lane tests four entries (one
+// 64-byte read, the pair of lanes reading one 128-byte line), what the two lanes decide travels as one word
+// exchanged by a single DPP swap, and a stack entry is one 8-byte LDS word pair written without branches
+// (an entry that is not pushed goes to a scratch slot of the ray's LDS area).  Same tree, same
+// (distance, rank) tie-break, same results as k_raycast_quad.
+#ifndef PAIR_STACK
+#define PAIR_STACK 18        // (node, distance) entries per ray in LDS; deeper ones go through the global spill area
+#endif
+#define PAIR_PENDING 16      // ring of postponed triangles per ray
+#define PAIR_STRIDE (2 * PAIR_STACK + PAIR_PENDING + 2)     // words per ray: stack pairs, ring, one scratch pair (even: 8-byte aligned)
+#ifndef PAIR_REFILL_MIN
+#define PAIR_REFILL_MIN 8    // refill once this many of the 32 rays are done
+#endif
+#ifndef PAIR_WAVES_PER_EU
+#define PAIR_WAVES_PER_EU 5
+#endif
+#ifndef PAIR_FLUSH
+#define PAIR_FLUSH 8
+#endif
+
+__device__ inline uint32_t pair_swap(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
+__device__ inline uint32_t pair_min_u32(uint32_t v) { return min(v, pair_swap(v)); }
+__device__ inline uint32_t pair_max_u32(uint32_t v) { return max(v, pair_swap(v)); }
+
+template <bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(PAIR_WAVES_PER_EU, PAIR_WAVES_PER_EU))) void
+k_raycast_pair(GeoView g, const float4 *rays, int first_photon, StepState *st,
+               int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint2 *spill_base, DeviceCounters *counters,
+               int big_chunk)
+{
+    const int nthreads = (int)st->n;
+    if ((long long)blockIdx.x * 32 >= nthreads) return;
+    uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
+    const int chunk = ((long long)nthreads > 4ll * big_chunk * (long long)gridDim.x) ? big_chunk : 32;
+    static_assert(PROP_BLOCK == WAVE, "one wave per workgroup");
+    static_assert((PAIR_PENDING & (PAIR_PENDING - 1)) == 0 && PAIR_FLUSH - 1 + 8 <= PAIR_PENDING && (PAIR_STRIDE & 1) == 0, "LDS layout");
+    __shared__ __attribute__((aligned(8))) uint32_t s_lds[32 * PAIR_STRIDE];
+    const unsigned lane = lane_id();
+    const unsigned j = lane & 1u, pshift = lane & ~1u, grp = lane >> 1;
+    const uint32_t low4 = j ? 0xFu : 0u;               // the partner's entries, when they come before this lane's
+    uint2 *stack = (uint2 *)(s_lds + grp * PAIR_STRIDE);                         // [PAIR_STACK] (node, distance bits)
+    uint32_t *pending = s_lds + grp * PAIR_STRIDE + 2 * PAIR_STACK;               // [PAIR_PENDING]
+    uint2 *const scratch_pair = (uint2 *)(pending + PAIR_PENDING);               // where an entry that is not pushed goes
+    uint32_t *const scratch_word = pending + PAIR_PENDING;
+    uint2 *spill = spill_base + ((size_t)blockIdx.x * 32 + grp) * COOP_SPILL;
+    LaneCounters cnt = {0, 0, 0, 0};
+
+    // per-ray state, identical in the 2 lanes of a pair
+    bool has_ray = false, active = false;
+    int slot = 0;
+    v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
+    v3 ra = mk3(0.f, 0.f, 0.f);
+    f32x2 rbx = {0.f, 0.f}, rby = {0.f, 0.f}, rbz = {0.f, 0.f};
+    uint32_t last_hit_w = WIDE_NONE;
+    int triangle_index = -1;
+    uint32_t best_rank = 0;
+    float min_distance = -1.0f;
+    float prune_t = cm_inff();
+    uint32_t cur = WIDE_NONE;
+    int sp = 0, npend = 0;
+    uint32_t phead = 0;
+    uint32_t loc_next = 0, loc_end = 0;
+    bool exhausted = false;
+
+    for (;;) {
+        // ---- refill idle pairs
+        unsigned long long idle_mask = __ballot(!has_ray && j == 0);
+        int n_idle = __popcll(idle_mask);
+        bool more = !exhausted || loc_next < loc_end;
+        if (more && (n_idle >= PAIR_REFILL_MIN || n_idle == 32)) {
+            if (loc_next >= loc_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work_counter, (uint32_t)chunk);
+                base = __shfl(base, 0);
+                if (base + (uint32_t)chunk >= (uint32_t)nthreads) exhausted = true;
+                loc_next = min(base, (uint32_t)nthreads);
+                loc_end = min(base + (uint32_t)chunk, (uint32_t)nthreads);
+            }
+            uint32_t idx = loc_next + (uint32_t)__popcll(idle_mask & ((1ull << pshift) - 1ull));
+            loc_next = min(loc_end, loc_next + (uint32_t)n_idle);
+            if (!has_ray && idx < loc_end) {
+                slot = first_photon + (int)idx;
+                const float4 *r = rays + 4 * (size_t)slot;
+                const float4 r0 = r[0], r1 = r[1];
+                if (__float_as_int(r1.w) == 0) {                 // (other slots were settled by k_ray_setup)
+                    const float4 r2 = r[2], r3 = r[3];
+                    origin = mk3(r0.x, r0.y, r0.z);
+                    direction = mk3(r1.x, r1.y, r1.z);
+                    { const int lh = __float_as_int(r0.w); last_hit_w = lh >= 0 ? (0x80000000u | (uint32_t)lh) : WIDE_NONE; }
+                    ra = mk3(r2.x, r2.y, r2.z);
+                    rbx = (f32x2){r3.x - ra.x, r3.x + ra.x};
+                    rby = (f32x2){r3.y - ra.y, r3.y + ra.y};
+                    rbz = (f32x2){r3.z - ra.z, r3.z + ra.z};
+                    triangle_index = -1;
+                    min_distance = -1.0f;
+                    prune_t = cm_inff();
+                    sp = 0;
+                    npend = 0;
+                    phead = 0;
+                    cur = 0;
+                    has_ray = true;
+                    active = true;
+                }
+            }
+        }
+        if (!__any(has_ray)) {
+            if (exhausted && loc_next >= loc_end) break;
+            continue;
+        }
+
+        // ---- node phase: every active pair visits one node per iteration
+        more = !exhausted || loc_next < loc_end;
+        const int stop_at = more ? max(0, __popcll(__ballot(active && j == 0)) - PAIR_REFILL_MIN) : 0;
+        do {
+            __builtin_amdgcn_s_setprio(3);       // a wave about to fetch its next node goes before waves that compute
+            if (!__any(sp > PAIR_STACK)) {
+                if (active && cur == WIDE_NONE) {
+                    while (sp > 0) {
+                        sp--;
+                        const uint2 se = stack[sp];
+                        if (!(__uint_as_float(se.y) > prune_t)) { cur = se.x; break; }
+                    }
+                    if (cur == WIDE_NONE) active = false;
+                }
+            } else if (active && cur == WIDE_NONE) {
+                while (sp > 0) {
+                    sp--;
+                    const uint2 se = sp < PAIR_STACK ? stack[sp] : spill[sp - PAIR_STACK];
+                    if (!(__uint_as_float(se.y) > prune_t)) { cur = se.x; break; }
+                }
+                if (cur == WIDE_NONE) active = false;
+            }
+            if (active) {
+                const uint4 *np = g.wnodes + 8 * (size_t)cur + 4 * j;       // this lane's four entries: 64 bytes
+                const uint4 e0 = np[0], e1 = np[1], e2 = np[2], e3 = np[3];
+                __builtin_amdgcn_s_setprio(0);
+                if (COUNT && j == 0) cnt.nodes += 8;
+                float t0, t1, t2, t3, f0, f1, f2, f3;
+                box_interval_pk(ra, rbx, rby, rbz, e0, t0, f0);
+                box_interval_pk(ra, rbx, rby, rbz, e1, t1, f1);
+                box_interval_pk(ra, rbx, rby, rbz, e2, t2, f2);
+                box_interval_pk(ra, rbx, rby, rbz, e3, t3, f3);
+                // intersect_node (mesh.h:16-34) with prune_t = +inf until something is hit
+                const bool p0 = (e0.w != WIDE_NONE) & !(t0 > f0) & !(t0 > prune_t);
+                const bool p1 = (e1.w != WIDE_NONE) & !(t1 > f1) & !(t1 > prune_t);
+                const bool p2 = (e2.w != WIDE_NONE) & !(t2 > f2) & !(t2 > prune_t);
+                const bool p3 = (e3.w != WIDE_NONE) & !(t3 > f3) & !(t3 > prune_t);
+                const bool l0 = p0 & ((int)e0.w < 0) & (e0.w != last_hit_w), i0 = p0 & ((int)e0.w >= 0);
+                const bool l1 = p1 & ((int)e1.w < 0) & (e1.w != last_hit_w), i1 = p1 & ((int)e1.w >= 0);
+                const bool l2 = p2 & ((int)e2.w < 0) & (e2.w != last_hit_w), i2 = p2 & ((int)e2.w >= 0);
+                const bool l3 = p3 & ((int)e3.w < 0) & (e3.w != last_hit_w), i3 = p3 & ((int)e3.w >= 0);
+                // the pair's word: bits 0-7 = entry k is a leaf to test, bits 8-15 = an inner node to visit
+                // (entry number = 4 * lane-in-pair + k)
+                const uint32_t own = ((l0 ? 0x001u : 0u) | (l1 ? 0x002u : 0u) | (l2 ? 0x004u : 0u) | (l3 ? 0x008u : 0u) |
+                                      (i0 ? 0x100u : 0u) | (i1 ? 0x200u : 0u) | (i2 ? 0x400u : 0u) | (i3 ? 0x800u : 0u)) << (4u * j);
+                const uint32_t pm = own | pair_swap(own);
+                // postponed triangles: ring slots after the ones already there, lower entries first; an entry
+                // that is no leaf writes to the scratch word instead (no branches)
+                {
+                    uint32_t off = phead + (uint32_t)npend + __popc(pm & low4);
+                    uint32_t *a0 = l0 ? pending + (off & (PAIR_PENDING - 1u)) : scratch_word; off += l0 ? 1u : 0u;
+                    uint32_t *a1 = l1 ? pending + (off & (PAIR_PENDING - 1u)) : scratch_word; off += l1 ? 1u : 0u;
+                    uint32_t *a2 = l2 ? pending + (off & (PAIR_PENDING - 1u)) : scratch_word; off += l2 ? 1u : 0u;
+                    uint32_t *a3 = l3 ? pending + (off & (PAIR_PENDING - 1u)) : scratch_word;
+                    *a0 = e0.w & 0x7FFFFFFFu; *a1 = e1.w & 0x7FFFFFFFu; *a2 = e2.w & 0x7FFFFFFFu; *a3 = e3.w & 0x7FFFFFFFu;
+                    npend += __popc(pm & 0xFFu);
+                }
+                cur = WIDE_NONE;
+                const uint32_t mi = pm >> 8;                 // inner entries by entry number
+                if (mi) {
+                    // nearest inner child: smallest (distance, entry) key -- the entry number replaces the
+                    // low 3 mantissa bits, which only matters for the ORDER of the visits
+                    const uint32_t eb = 4u * j;
+                    const uint32_t k0 = i0 ? ((__float_as_uint(t0) & ~7u) | eb) : 0xFFFFFFFFu;
+                    const uint32_t k1 = i1 ? ((__float_as_uint(t1) & ~7u) | (eb + 1u)) : 0xFFFFFFFFu;
+                    const uint32_t k2 = i2 ? ((__float_as_uint(t2) & ~7u) | (eb + 2u)) : 0xFFFFFFFFu;
+                    const uint32_t k3 = i3 ? ((__float_as_uint(t3) & ~7u) | (eb + 3u)) : 0xFFFFFFFFu;
+                    const uint32_t ne = pair_min_u32(min(min(k0, k1), min(k2, k3))) & 7u;        // entry number of the nearest
+                    const uint32_t nk = ne - eb;                                                  // 0..3 when it is this lane's
+                    const uint32_t mine = nk == 0u ? e0.w : nk == 1u ? e1.w : nk == 2u ? e2.w : nk == 3u ? e3.w : 0u;
+                    cur = pair_max_u32(mine);
+                    // every other inner child goes on the stack at its own slot
+                    const uint32_t mo = mi & ~(1u << ne);
+                    int pos = sp + __popc(mo & low4);
+                    sp += __popc(mo);
+                    const bool q0 = i0 & (nk != 0u), q1 = i1 & (nk != 1u), q2 = i2 & (nk != 2u), q3 = i3 & (nk != 3u);
+                    if (!__any(sp > PAIR_STACK)) {
+                        // every ray of the wave stays inside its LDS stack (almost always): four unconditional stores
+                        uint2 *s0 = q0 ? stack + pos : scratch_pair; pos += q0 ? 1 : 0;
+                        uint2 *s1 = q1 ? stack + pos : scratch_pair; pos += q1 ? 1 : 0;
+                        uint2 *s2 = q2 ? stack + pos : scratch_pair; pos += q2 ? 1 : 0;
+                        uint2 *s3 = q3 ? stack + pos : scratch_pair;
+                        *s0 = make_uint2(e0.w, __float_as_uint(t0)); *s1 = make_uint2(e1.w, __float_as_uint(t1));
+                        *s2 = make_uint2(e2.w, __float_as_uint(t2)); *s3 = make_uint2(e3.w, __float_as_uint(t3));
+                    } else {
+#define PAIR_PUSH(q, e, t)                                                                                              \
+                        if (q) {                                                                                        \
+                            if (pos < PAIR_STACK) stack[pos] = make_uint2(e.w, __float_as_uint(t));                     \
+                            else if (pos < PAIR_STACK + COOP_SPILL) { spill[pos - PAIR_STACK] = make_uint2(e.w, __float_as_uint(t)); \
+                                                                      if (COUNT) atomicAdd(&counters->stack_spills, 1ull); } \
+                            pos++;                                                                                      \
+                        }
+                        PAIR_PUSH(q0, e0, t0) PAIR_PUSH(q1, e1, t1) PAIR_PUSH(q2, e2, t2) PAIR_PUSH(q3, e3, t3)
+#undef PAIR_PUSH
+                        if (sp > PAIR_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
+                            triangle_index = HIT_RETRY;
+                            active = false; npend = 0; cur = WIDE_NONE; sp = 0;
+                        }
+                    }
+                }
+            }
+        } while (!__any(npend >= PAIR_FLUSH) && __popcll(__ballot(active && j == 0)) > stop_at);
+        __builtin_amdgcn_wave_barrier();      // (scheduling fence: the lanes of a pair exchange data through LDS)
+
+        // ---- leaf phase: up to 2 postponed triangles of a ray at once, one per lane
+        while (__any(npend > 0)) {
+            if (npend > 0) {
+                const int take = min(npend, 2);
+                bool hit = false;
+                float distance = 0.0f;
+                uint32_t tri = 0, rank = 0xFFFFFFFFu;
+                if ((int)j < take) {
+                    tri = pending[(phead + j) & (PAIR_PENDING - 1u)];
+                    if (COUNT) cnt.tris++;
+                    const float4 *tp = g.tri + TRI_STRIDE * (size_t)tri;
+                    float4 a = tp[0], b = tp[1], c = tp[2];
+                    hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
+                    rank = __float_as_uint(c.w);
+                }
+                // distances are positive: their bit patterns order like the floats
+                const uint32_t dkey = hit ? __float_as_uint(distance) : 0x7F800000u;
+                const uint32_t dmin = pair_min_u32(dkey);
+                if (dmin != 0x7F800000u) {
+                    const float dm = __uint_as_float(dmin);
+                    const bool cand = hit && dkey == dmin;
+                    const uint32_t rm = pair_min_u32(cand ? rank : 0xFFFFFFFFu);
+                    const uint32_t wtri = pair_max_u32((cand && rank == rm) ? tri + 1u : 0u) - 1u;
+                    if (triangle_index == -1 || dm < min_distance || (dm == min_distance && rm < best_rank)) {
+                        triangle_index = (int)wtri;
+                        min_distance = dm;
+                        prune_t = dm;
+                        best_rank = rm;
+                    }
+                }
+                phead = (phead + (uint32_t)take) & (PAIR_PENDING - 1u);
+                npend -= take;
+            }
+        }
+
+        // ---- retire finished rays
+        if (has_ray && !active) {
+            if (j == 0) {
+                hit_triangle[slot] = triangle_index;                 // record index, or a HIT_* code
+                hit_distance[slot] = min_distance;
+                if (triangle_index == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
+            }
+            has_ray = false;
+        }
+    }
+
+    if (COUNT) {
+        unsigned long long nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
+        if (lane == 0) {
+            atomicAdd(&counters->nodes_visited, nd);
+            atomicAdd(&counters->triangles_tested, tr);
+        }
+    }
+}
+
 // ---- fused tail: all remaining steps of the last few photons, eight lanes per photon ---------------
 // Once fewer than 64*16*8 photons are alive the reference finishes them in ONE launch
 // (chroma/gpu/photon.py:227-230).  Per-step launches are a poor fit for that tail -- a few thousand
@@ -1710,14 +1985,33 @@ __device__ inline uint32_t wave_reserve(uint32_t *counter, bool pred, bool &any)
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// copy_photons (propagate.cu:81-114)
-__global__ void k_copy_photons(PhotonView src, PhotonView dst, int first_photon, int nthreads, uint32_t target_flag, uint32_t *counter)
+// copy_photons (propagate.cu:81-114): one atomic per block of COPY_ITEMS * 256 photons, as k_copy_hits below
+__global__ __launch_bounds__(256) void
+k_copy_photons(PhotonView src, PhotonView dst, int first_photon, int nthreads, uint32_t target_flag, uint32_t *counter)
 {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    bool pred = (id < nthreads) && (src.flags[first_photon + id] & target_flag);
-    bool any;
-    uint32_t off = wave_reserve(counter, pred, any);
-    if (pred) copy_photon(src, (size_t)first_photon + id, dst, off);
+    __shared__ uint32_t s_wave[256 / WAVE + 1];
+    const long long base = (long long)blockIdx.x * (16 * 256);
+    const unsigned lane = lane_id(), wave = threadIdx.x / WAVE;
+    uint32_t take = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const long long id = base + (long long)k * 256 + threadIdx.x;
+        if (id < nthreads && (src.flags[first_photon + id] & target_flag)) { take |= 1u << k; mine++; }
+    }
+    uint32_t incl = mine;
+    for (int off = 1; off < WAVE; off <<= 1) { uint32_t v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
+    if (lane == WAVE - 1) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (unsigned w = 0; w < 256 / WAVE; w++) { uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
+        s_wave[256 / WAVE] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t off = s_wave[256 / WAVE] + s_wave[wave] + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (take & (1u << k)) copy_photon(src, (size_t)first_photon + (size_t)(base + (long long)k * 256 + threadIdx.x), dst, off++);
 }
 
 // copy_photon_queue (propagate.cu:116-144)
@@ -1754,18 +2048,45 @@ k_count_hits(GeoView g, const uint32_t *flags, const int32_t *last_hit, int firs
     if (threadIdx.x == 0 && s_total) atomicAdd(counter, s_total);
 }
 
-// copy_photon_hits (propagate.cu:176-214)
-__global__ void k_copy_hits(GeoView g, PhotonView src, PhotonView dst, int32_t *channels, int first_photon, int nphotons,
-                            uint32_t detection_state, uint32_t *counter)
+// copy_photon_hits (propagate.cu:176-214).  A block looks at COPY_ITEMS * 256 photons and reserves its
+// output span with ONE atomic (the reference's one atomic per detected photon -- or one per wave -- on a
+// single word costs 18 ms for 1e8 photons: a hot word serves ~88 atomics per microsecond).
+#define COPY_ITEMS 16
+__global__ __launch_bounds__(256) void
+k_copy_hits(GeoView g, PhotonView src, PhotonView dst, int32_t *channels, int first_photon, int nphotons,
+            uint32_t detection_state, uint32_t *counter)
 {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    int ch = -1;
-    if (id < nphotons) ch = hit_channel(g, src.flags[first_photon + id], src.last_hit_triangles[first_photon + id], detection_state);
-    bool pred = ch >= 0, any;
-    uint32_t off = wave_reserve(counter, pred, any);
-    if (pred) {
-        copy_photon(src, (size_t)first_photon + id, dst, off);
-        channels[off] = ch;
+    __shared__ uint32_t s_wave[256 / WAVE + 1];
+    const long long base = (long long)blockIdx.x * (COPY_ITEMS * 256);
+    const unsigned lane = lane_id(), wave = threadIdx.x / WAVE;
+    int ch[COPY_ITEMS];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < COPY_ITEMS; k++) {
+        const long long id = base + (long long)k * 256 + threadIdx.x;
+        ch[k] = -1;
+        if (id < nphotons) ch[k] = hit_channel(g, src.flags[first_photon + id], src.last_hit_triangles[first_photon + id], detection_state);
+        mine += ch[k] >= 0;
+    }
+    // exclusive prefix of `mine` over the block: wave scan, then the waves' totals through LDS
+    uint32_t incl = mine;
+    for (int off = 1; off < WAVE; off <<= 1) { uint32_t v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
+    if (lane == WAVE - 1) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (unsigned w = 0; w < 256 / WAVE; w++) { uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
+        s_wave[256 / WAVE] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t off = s_wave[256 / WAVE] + s_wave[wave] + incl - mine;
+#pragma unroll
+    for (int k = 0; k < COPY_ITEMS; k++) {
+        if (ch[k] >= 0) {
+            copy_photon(src, (size_t)first_photon + (size_t)(base + (long long)k * 256 + threadIdx.x), dst, off);
+            channels[off] = ch[k];
+            off++;
+        }
     }
 }
 
@@ -2008,6 +2329,14 @@ static int launch_propagate(chroma_ctx *ctx, chroma_geometry *geom, PhotonView p
     return launch_propagate_t<false>(ctx, geom, pv, first, nthreads, in_q, out_q, rng, max_steps, use_weights, scatter_first);
 }
 
+// the per-ray slices of global memory for stack entries beyond the LDS part: every cooperative walk indexes
+// it with (wave * rays-per-wave + ray) * COOP_SPILL, so it is sized for the largest grid of any of them
+static size_t spill_entries(const chroma_ctx *ctx)
+{
+    size_t rays = std::max(std::max((size_t)ctx->coop_waves * 8, (size_t)ctx->quad_waves * 16), (size_t)ctx->pair_waves * 32);
+    return rays * COOP_SPILL;
+}
+
 // one step for many photons: ray cast and physics as two launches
 // One step as ray set-up + ray cast + physics (+ the strict walk and the physics of the few rays that
 // need it), all reading the photon count and the launch policy from ctx->d_step (k_step_begin).
@@ -2023,20 +2352,23 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (need > STACK_LDS + STACK_SCRATCH)
         return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
     const bool have_wide = geom->view.wnodes != nullptr;
-    const bool quad = ctx->wide_walk == CHROMA_WALK_QUAD && have_wide && geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
-    const bool coop = !quad && (ctx->wide_walk == CHROMA_WALK_COOP || ctx->wide_walk == CHROMA_WALK_QUAD) && have_wide &&
+    const bool pair = ctx->wide_walk == CHROMA_WALK_PAIR && have_wide && geom->wide_stack_need <= PAIR_STACK + COOP_SPILL;
+    const bool quad = !pair && (ctx->wide_walk == CHROMA_WALK_QUAD || ctx->wide_walk == CHROMA_WALK_PAIR) && have_wide &&
                       geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
-    const bool wide = !coop && !quad && ctx->wide_walk != CHROMA_WALK_REFERENCE && have_wide && geom->wide_stack_need <= WIDE_STACK + WIDE_SPILL;
+    const bool coop = !pair && !quad && (ctx->wide_walk == CHROMA_WALK_COOP || ctx->wide_walk == CHROMA_WALK_QUAD) && have_wide &&
+                      geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
+    const bool wide = !pair && !coop && !quad && ctx->wide_walk != CHROMA_WALK_REFERENCE && have_wide && geom->wide_stack_need <= WIDE_STACK + WIDE_SPILL;
     if (wide && !ctx->wide_spill) {
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipMalloc((void **)&ctx->wide_spill, (size_t)ctx->wide_waves * WIDE_SPILL * PROP_BLOCK * sizeof(uint2)));
     }
-    if ((coop || quad) && !ctx->coop_spill) {
+    if ((coop || quad || pair) && !ctx->coop_spill) {
         HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, (size_t)ctx->coop_waves * 16 * COOP_SPILL * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, spill_entries(ctx) * sizeof(uint2)));
     }
     // persistent ray cast: enough waves to fill the chip, each pulling rays from the queue
-    unsigned waves = quad ? (unsigned)std::min<long long>((n_upper + 15) / 16, (long long)ctx->quad_waves)
+    unsigned waves = pair ? (unsigned)std::min<long long>((n_upper + 31) / 32, (long long)ctx->pair_waves)
+                   : quad ? (unsigned)std::min<long long>((n_upper + 15) / 16, (long long)ctx->quad_waves)
                    : coop ? (unsigned)std::min<long long>((n_upper + 7) / 8, (long long)ctx->coop_waves)
                           : (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK,
                                                           (long long)(wide ? ctx->wide_waves : ctx->persistent_waves));
@@ -2054,7 +2386,10 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (ev) HIP_TRY(hipEventRecord(ev[3], ctx->stream));        // the ray-cast kernel proper is timed from here
 #define RAYCAST_LAUNCH(COUNT)                                                                                          \
     do {                                                                                                               \
-        if (quad)                                                                                                      \
+        if (pair)                                                                                                      \
+            hipLaunchKernelGGL((k_raycast_pair<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
+                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
+        else if (quad)                                                                                                 \
             hipLaunchKernelGGL((k_raycast_quad<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
         else if (coop)                                                                                                 \
@@ -2101,7 +2436,7 @@ static int launch_tail(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, lo
         return CHROMA_OK;
     if (!ctx->coop_spill) {
         HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, (size_t)ctx->coop_waves * 16 * COOP_SPILL * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, spill_entries(ctx) * sizeof(uint2)));
     }
     unsigned waves = (unsigned)std::min<long long>((n_upper + 7) / 8, (long long)ctx->coop_waves);
     if ((long long)waves * 8 < n_upper) return CHROMA_OK;          // (cannot happen below 8192 photons)
@@ -2302,10 +2637,13 @@ int chroma_init(int device, chroma_ctx **out)
         ctx->coop_waves = prop.multiProcessorCount * coop_per_cu;
         int quad_per_cu = 4 * QUAD_WAVES_PER_EU;
         if (const char *e = getenv("CHROMA_QUAD_WAVES_PER_CU")) quad_per_cu = std::max(1, atoi(e));
-        ctx->quad_waves = std::min(prop.multiProcessorCount * quad_per_cu, ctx->coop_waves);      // (shares the spill area)
+        ctx->quad_waves = prop.multiProcessorCount * quad_per_cu;
+        int pair_per_cu = 4 * PAIR_WAVES_PER_EU;
+        if (const char *e = getenv("CHROMA_PAIR_WAVES_PER_CU")) pair_per_cu = std::max(1, atoi(e));
+        ctx->pair_waves = prop.multiProcessorCount * pair_per_cu;
         if (const char *e = getenv("CHROMA_WALK"))
             ctx->wide_walk = !strcmp(e, "reference") ? CHROMA_WALK_REFERENCE : !strcmp(e, "wide") ? CHROMA_WALK_WIDE
-                           : !strcmp(e, "coop") ? CHROMA_WALK_COOP : CHROMA_WALK_QUAD;
+                           : !strcmp(e, "coop") ? CHROMA_WALK_COOP : !strcmp(e, "pair") ? CHROMA_WALK_PAIR : CHROMA_WALK_QUAD;
         if (const char *e = getenv("CHROMA_RAY_CHUNK")) ctx->ray_chunk = std::max(64, atoi(e));
         if (const char *e = getenv("CHROMA_COOP_CHUNK")) ctx->coop_chunk = std::max(8, atoi(e));
         if (const char *e = getenv("CHROMA_TAIL")) {      // coop (default) | split | fused (the lane-per-photon k_propagate)
@@ -2757,7 +3095,7 @@ int chroma_copy_photons(chroma_ctx *ctx, int32_t first_photon, int32_t nthreads,
     rc = check_photons(dst, false); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 4, ctx->stream));
     if (nthreads > 0) {
-        hipLaunchKernelGGL(k_copy_photons, dim3((nthreads + 255) / 256), dim3(256), 0, ctx->stream, to_view(src), to_view(dst),
+        hipLaunchKernelGGL(k_copy_photons, dim3((unsigned)(((long long)nthreads + 16 * 256 - 1) / (16 * 256))), dim3(256), 0, ctx->stream, to_view(src), to_view(dst),
                            first_photon, nthreads, target_flag, ctx->d_words);
         HIP_TRY(hipGetLastError());
     }
@@ -2805,7 +3143,7 @@ int chroma_copy_photon_hits(chroma_ctx *ctx, chroma_geometry *geom, int32_t firs
     rc = check_photons(dst, false); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 4, ctx->stream));
     if (nphotons > 0) {
-        hipLaunchKernelGGL(k_copy_hits, dim3((nphotons + 255) / 256), dim3(256), 0, ctx->stream, geom->view, to_view(src),
+        hipLaunchKernelGGL(k_copy_hits, dim3((unsigned)(((long long)nphotons + COPY_ITEMS * 256 - 1) / (COPY_ITEMS * 256))), dim3(256), 0, ctx->stream, geom->view, to_view(src),
                            to_view(dst), d_channels, first_photon, nphotons, detection_state, ctx->d_words);
         HIP_TRY(hipGetLastError());
     }
@@ -2850,7 +3188,7 @@ static int distance_to_mesh_fast(chroma_ctx *ctx, chroma_geometry *geom, int32_t
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_queues(ctx, (size_t)n); if (rc) return rc;
     if (!ctx->coop_spill)
-        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, (size_t)ctx->coop_waves * 16 * COOP_SPILL * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, spill_entries(ctx) * sizeof(uint2)));
     StepState *st = ctx->d_step;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_step_set, dim3(1), dim3(1), 0, ctx->stream, st, (uint32_t)n);
@@ -2930,7 +3268,8 @@ int chroma_set_counting(chroma_ctx *ctx, int32_t enabled)
 int chroma_set_walk(chroma_ctx *ctx, int32_t mode)
 {
     if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
-    if (mode != CHROMA_WALK_REFERENCE && mode != CHROMA_WALK_WIDE && mode != CHROMA_WALK_COOP && mode != CHROMA_WALK_QUAD)
+    if (mode != CHROMA_WALK_REFERENCE && mode != CHROMA_WALK_WIDE && mode != CHROMA_WALK_COOP && mode != CHROMA_WALK_QUAD &&
+        mode != CHROMA_WALK_PAIR)
         return set_error(CHROMA_ERR_INVALID, "unknown walk mode %d", mode);
     ctx->wide_walk = mode;
     return CHROMA_OK;
@@ -2990,7 +3329,8 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         int step = 0, next_check = 1, steps_timed = 0;
         bool done = false, tail_done = false;
         const long long few = (long long)PROP_BLOCK * 16 * 8;
-        const bool fused_tail = ctx->fused_tail && (ctx->wide_walk == CHROMA_WALK_COOP || ctx->wide_walk == CHROMA_WALK_QUAD);    // (the cross-check walks keep per-step launches)
+        const bool fused_tail = ctx->fused_tail && (ctx->wide_walk == CHROMA_WALK_COOP || ctx->wide_walk == CHROMA_WALK_QUAD ||
+                                                    ctx->wide_walk == CHROMA_WALK_PAIR);    // (the cross-check walks keep per-step launches)
         int tail_step = -1;                  // the step at which the fused tail was launched
         while (step < max_steps && !done) {
             if (fused_tail && n_upper < few) {

@@ -87,7 +87,7 @@ class Context(object):
 
     def set_walk(self, mode):
         """'quad' (default), 'coop', 'wide' or 'reference': how the per-step ray cast walks (same results)."""
-        _lib.check(self._lib.chroma_set_walk(self.handle, {'reference': 0, 'wide': 1, 'coop': 2, 'quad': 3}[mode]))
+        _lib.check(self._lib.chroma_set_walk(self.handle, {'reference': 0, 'wide': 1, 'coop': 2, 'quad': 3, 'pair': 4}[mode]))
 
     def set_tail(self, mode):
         """'coop' (default), 'split' or 'fused': how propagate() finishes -- or, with 'fused', runs -- a batch."""

@@ -396,6 +396,7 @@ int chroma_set_counting(chroma_ctx *ctx, int32_t enabled);
 #define CHROMA_WALK_WIDE      1
 #define CHROMA_WALK_COOP      2
 #define CHROMA_WALK_QUAD      3   /* the wide tree with four lanes per ray, two child entries per lane */
+#define CHROMA_WALK_PAIR      4   /* the wide tree with two lanes per ray, four child entries per lane  */
 int chroma_set_walk(chroma_ctx *ctx, int32_t mode);
 
 /* How chroma_propagate finishes a batch and, with FUSED, how it runs it at all (same results; for

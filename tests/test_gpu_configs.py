@@ -147,7 +147,7 @@ def batch_properties(gpu, cfg, n, id_base, wavelength=400.0, max_nan_fraction=0.
     return stats, nhits.value
 
 
-def walks_agree(gpu, cfg, n, id_base, wavelength=400.0, walks=('reference',)):
+def walks_agree(gpu, cfg, n, id_base, wavelength=400.0, walks=('pair', 'reference')):
     """The 4-lane walk over the 8-wide tree against the other walks (default: the literal reference
     walk over the reference tree) on one batch."""
     gp, _ = propagate_device_bomb(gpu, cfg, n, id_base, wavelength=wavelength)
@@ -181,7 +181,7 @@ def test_c3_full_batch_properties(gpu, c3):
 def test_c2_one_million_photons_match_the_oracle(gpu, oracle_mod, c2):
     gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c2, 1_000_000, 'C2 demo.detector(), 1e6 photons')
     assert 0.03 < np.count_nonzero(got.flags & event.SURFACE_DETECT) / 1e6 < 0.15
-    walks_agree(gpu, c2, 1_000_000, id_base=0, walks=('coop', 'wide', 'reference'))
+    walks_agree(gpu, c2, 1_000_000, id_base=0, walks=('pair', 'coop', 'wide', 'reference'))
 
 
 def test_c2_batch_properties(gpu, c2):
@@ -204,4 +204,4 @@ def test_c5_full_batch_matches_the_oracle(gpu, oracle_mod, c5):
 
 def test_c5_full_batch_properties(gpu, c5):
     batch_properties(gpu, c5, 10_000_000, id_base=1 << 34, wavelength=350.0, max_nan_fraction=1e-4)
-    walks_agree(gpu, c5, 2_000_000, id_base=1 << 34, wavelength=350.0, walks=('coop', 'reference'))
+    walks_agree(gpu, c5, 2_000_000, id_base=1 << 34, wavelength=350.0, walks=('pair', 'coop', 'reference'))

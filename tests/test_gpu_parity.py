@@ -78,7 +78,7 @@ def test_large_batch_uses_per_step_launches(gpu, oracle_mod, tiny_geometry):
     assert stats['triangles_tested'] <= 1.3 * ostats['triangles_tested']
     # the same batch with the other two ray casts -- one lane per ray over the wide tree, and the
     # reference tree in the reference's order: identical results
-    for mode in ('coop', 'wide', 'reference'):
+    for mode in ('pair', 'coop', 'wide', 'reference'):
         gpu.get_context().set_walk(mode)
         try:
             gp2 = gpu.GPUPhotons(ph)
@@ -474,7 +474,7 @@ def test_exact_ties_follow_the_reference_test_order(gpu, oracle_mod, tiny_geomet
     from chroma_amd.gpu.geometry import pack_geometry
     dist, tri, _ = oracle_mod.distance_to_mesh(pack_geometry(tiny_geometry), ph.pos[:4000], ph.dir[:4000])
     assert (tri >= 0).mean() > 0.9
-    for mode in ('coop', 'wide', 'reference'):
+    for mode in ('pair', 'coop', 'wide', 'reference'):
         gpu.get_context().set_walk(mode)
         try:
             gp2 = gpu.GPUPhotons(ph)
@@ -545,7 +545,7 @@ def test_large_batch_properties(gpu, oracle_mod, tiny_geometry):
     ph = oracle_mod.generate_bomb(n, seed=77, wavelength_lo=400.0, wavelength_hi=650.0)
     gg = gpu.GPUDetector(tiny_geometry)
     results = {}
-    for mode in ('quad', 'quad', 'coop', 'wide', 'reference'):
+    for mode in ('quad', 'quad', 'pair', 'coop', 'wide', 'reference'):
         gpu.get_context().set_walk(mode)
         try:
             gp = gpu.GPUPhotons(ph)
@@ -556,7 +556,7 @@ def test_large_batch_properties(gpu, oracle_mod, tiny_geometry):
         if mode in results:
             assert_bit_exact(out, results[mode], 'repeat of %s' % mode)
         results[mode] = out
-    for mode in ('coop', 'wide', 'reference'):
+    for mode in ('pair', 'coop', 'wide', 'reference'):
         assert_bit_exact(results[mode], results['quad'], '%s vs quad' % mode)
     out = results['quad']
     assert ((out.flags & event.TERMINAL_MASK) != 0).mean() > 0.999

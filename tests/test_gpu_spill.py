@@ -42,17 +42,18 @@ def test_large_batch_through_the_spill_area(gpu, oracle_mod, tiny_geometry):
     assert np.array_equal(gp.rng_counters.get(), counters)
     assert stats['photon_steps'] == ostats['photon_steps'] and stats['launches'] == ostats['launches']
     assert stats['stack_spills'] > 10000, 'the variant did not spill: %r' % (stats,)
-    gpu.get_context().set_walk('coop')
-    try:
-        gp2 = gpu.GPUPhotons(ph)
-        stats2 = {}
-        gpu.get_context().set_counting(True)
-        gp2.propagate(gg, gpu.get_rng_states(64 * 1024, seed=12345), max_steps=30, stats=stats2)
-        gpu.get_context().set_counting(False)
-    finally:
-        gpu.get_context().set_walk('quad')
-    assert_bit_exact(gp2.get(), want, 'stack4, tiny 60k, coop walk')
-    assert stats2['stack_spills'] > 10000
+    for walk in ('coop', 'pair'):
+        gpu.get_context().set_walk(walk)
+        try:
+            gp2 = gpu.GPUPhotons(ph)
+            stats2 = {}
+            gpu.get_context().set_counting(True)
+            gp2.propagate(gg, gpu.get_rng_states(64 * 1024, seed=12345), max_steps=30, stats=stats2)
+            gpu.get_context().set_counting(False)
+        finally:
+            gpu.get_context().set_walk('quad')
+        assert_bit_exact(gp2.get(), want, 'stack4, tiny 60k, %s walk' % walk)
+        assert stats2['stack_spills'] > 10000, walk
 
 
 @pytest.mark.parametrize('count', ['large', 'small'])
