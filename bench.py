@@ -141,6 +141,15 @@ def main():
         packed, shm_path = publish_packed_geometry(build_packed, 'bench_' + args.config, local_rank, dist.barrier)
         # the uploads (validation, staging) run in every rank at once: share the cores from here on
         os.environ.setdefault('CHROMA_HOST_THREADS', str(max(4, effective_cores() // max(1, local_world))))
+    elif os.environ.get('CHROMA_BENCH_GEOMETRY_CACHE'):
+        # repeated runs on one box (A/B series, counter passes): the packed geometry is kept between them
+        from chroma_amd.gpu.geometry import PackedGeometry
+        cache = os.path.join(os.environ['CHROMA_BENCH_GEOMETRY_CACHE'], args.config)
+        if os.path.exists(os.path.join(cache, 'desc.json')):
+            packed = PackedGeometry.load(cache, mmap=True)
+        else:
+            packed = build_packed()
+            packed.save(cache)
     else:
         packed = build_packed()
     t_build = time.time() - t0

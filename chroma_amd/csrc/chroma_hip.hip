@@ -785,7 +785,7 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
 
         // ---- node phase: every active group visits one node per iteration
         more = !exhausted || loc_next < loc_end;
-        const int stop_at = more ? max(0, __popcll(__ballot(active && j == 0)) - COOP_REFILL_MIN) : 0;
+        const int stop_at = more ? max(0, (int)__popcll(__ballot(active && j == 0)) - (int)COOP_REFILL_MIN) : 0;
         do {
             if (active && cur == WIDE_NONE) {
                 // next entry that can still hold a nearer hit
@@ -901,7 +901,10 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #ifndef QUAD_PENDING
 #define QUAD_PENDING 16      // ring of postponed triangles per ray (a power of two; 32 costs residency, measured slower)
 #endif
-#define QUAD_STRIDE (2 * COOP_STACK + QUAD_PENDING + 1)     // words per ray, +1 staggers the banks
+#ifndef QUAD_STACK
+#define QUAD_STACK COOP_STACK    // (node, distance) entries per ray in LDS
+#endif
+#define QUAD_STRIDE (2 * QUAD_STACK + QUAD_PENDING + 1)     // words per ray, +1 staggers the banks
 #ifndef QUAD_REFILL_MIN
 #define QUAD_REFILL_MIN 4    // refill once this many of the 16 rays are done
 #endif
@@ -934,14 +937,14 @@ __device__ inline uint32_t quad_max_u32(uint32_t v)
 // box_interval_fast with the two faces of an axis as one packed operation (v_pk_fma_f32: same fused
 // multiply-add per half, half the issue slots)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ inline void box_interval_pk(const v3 &a, f32x2 bx, f32x2 by, f32x2 bz, uint4 nd, float &tmin, float &tmax)
+__device__ inline void box_interval_pk(float ax, float ay, float az, f32x2 bx, f32x2 by, f32x2 bz, uint4 nd, float &tmin, float &tmax)
 {
     f32x2 qx = {(float)(nd.x & 0xFFFFu), (float)(nd.x >> 16)};
     f32x2 qy = {(float)(nd.y & 0xFFFFu), (float)(nd.y >> 16)};
     f32x2 qz = {(float)(nd.z & 0xFFFFu), (float)(nd.z >> 16)};
-    const f32x2 tx = __builtin_elementwise_fma(qx, (f32x2){a.x, a.x}, bx);
-    const f32x2 ty = __builtin_elementwise_fma(qy, (f32x2){a.y, a.y}, by);
-    const f32x2 tz = __builtin_elementwise_fma(qz, (f32x2){a.z, a.z}, bz);
+    const f32x2 tx = __builtin_elementwise_fma(qx, (f32x2){ax, ax}, bx);
+    const f32x2 ty = __builtin_elementwise_fma(qy, (f32x2){ay, ay}, by);
+    const f32x2 tz = __builtin_elementwise_fma(qz, (f32x2){az, az}, bz);
     tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)),
                            __builtin_fmaxf(__builtin_fminf(tz.x, tz.y), 0.0f));
     tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)),
@@ -974,8 +977,8 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     // 2/3 = it is an inner node to visit.  (Wave ballots cost two VALU operations each plus the extract.)
     const uint32_t jbit = 1u << j, below2 = (jbit - 1u) * 0x11u;
     uint32_t *stack_n = s_lds + grp * QUAD_STRIDE;
-    float *stack_t = (float *)(stack_n + COOP_STACK);
-    uint32_t *pending = stack_n + 2 * COOP_STACK;
+    float *stack_t = (float *)(stack_n + QUAD_STACK);
+    uint32_t *pending = stack_n + 2 * QUAD_STACK;
     uint2 *spill = spill_base + ((size_t)blockIdx.x * 16 + grp) * COOP_SPILL;
     LaneCounters cnt = {0, 0, 0, 0};
 
@@ -983,7 +986,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     bool has_ray = false, active = false;
     int slot = 0;
     v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
-    v3 ra = mk3(0.f, 0.f, 0.f);             // RayFast::a, and {blo, bhi} per axis
+    float rax = 0.f, ray_ = 0.f, raz = 0.f; // RayFast::a (three scalars: as a struct it ended up in LDS), and {blo, bhi} per axis
     f32x2 rbx = {0.f, 0.f}, rby = {0.f, 0.f}, rbz = {0.f, 0.f};
     uint32_t last_hit_w = WIDE_NONE;        // the leaf word of the photon's last hit (never entered)
     int triangle_index = -1;
@@ -1021,10 +1024,10 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     origin = mk3(r0.x, r0.y, r0.z);
                     direction = mk3(r1.x, r1.y, r1.z);
                     { const int lh = __float_as_int(r0.w); last_hit_w = lh >= 0 ? (0x80000000u | (uint32_t)lh) : WIDE_NONE; }
-                    ra = mk3(r2.x, r2.y, r2.z);
-                    rbx = (f32x2){r3.x - ra.x, r3.x + ra.x};
-                    rby = (f32x2){r3.y - ra.y, r3.y + ra.y};
-                    rbz = (f32x2){r3.z - ra.z, r3.z + ra.z};
+                    rax = r2.x; ray_ = r2.y; raz = r2.z;
+                    rbx = (f32x2){r3.x - rax, r3.x + rax};
+                    rby = (f32x2){r3.y - ray_, r3.y + ray_};
+                    rbz = (f32x2){r3.z - raz, r3.z + raz};
                     triangle_index = -1;
                     min_distance = -1.0f;
                     prune_t = cm_inff();
@@ -1044,13 +1047,13 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
 
         // ---- node phase: every active quad visits one node per iteration
         more = !exhausted || loc_next < loc_end;
-        const int stop_at = more ? max(0, __popcll(__ballot(active && j == 0)) - QUAD_REFILL_MIN) : 0;
+        const int stop_at = more ? max(0, (int)__popcll(__ballot(active && j == 0)) - (int)QUAD_REFILL_MIN) : 0;
         do {
 #if QUAD_SETPRIO
             __builtin_amdgcn_s_setprio(3);       // a wave about to fetch its next node goes before waves that compute
 #endif
 #if QUAD_UNIFORM_SPILL
-            if (!__any(sp > COOP_STACK)) {
+            if (!__any(sp > QUAD_STACK)) {
                 if (active && cur == WIDE_NONE) {
                     while (sp > 0) {
                         sp--;
@@ -1066,8 +1069,8 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 while (sp > 0) {
                     sp--;
                     uint32_t n; float t;
-                    if (sp < COOP_STACK) { n = stack_n[sp]; t = stack_t[sp]; }
-                    else { uint2 se = spill[sp - COOP_STACK]; n = se.x; t = __uint_as_float(se.y); }
+                    if (sp < QUAD_STACK) { n = stack_n[sp]; t = stack_t[sp]; }
+                    else { uint2 se = spill[sp - QUAD_STACK]; n = se.x; t = __uint_as_float(se.y); }
                     if (!(t > prune_t)) { cur = n; break; }
                 }
                 if (cur == WIDE_NONE) active = false;
@@ -1080,8 +1083,8 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #endif
                 if (COUNT && j == 0) cnt.nodes += 8;
                 float ta, tb, fa, fb;
-                box_interval_pk(ra, rbx, rby, rbz, ea, ta, fa);
-                box_interval_pk(ra, rbx, rby, rbz, eb, tb, fb);
+                box_interval_pk(rax, ray_, raz, rbx, rby, rbz, ea, ta, fa);
+                box_interval_pk(rax, ray_, raz, rbx, rby, rbz, eb, tb, fb);
                 // intersect_node (mesh.h:16-34) with prune_t = +inf until something is hit
                 const bool pa = (ea.w != WIDE_NONE) & !(ta > fa) & !(ta > prune_t);
                 const bool pb = (eb.w != WIDE_NONE) & !(tb > fb) & !(tb > prune_t);
@@ -1113,7 +1116,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     int pos = sp + __popc(mo & below2);
                     sp += __popc(mo);
 #if QUAD_UNIFORM_SPILL
-                    if (!__any(sp > COOP_STACK)) {
+                    if (!__any(sp > QUAD_STACK)) {
                         // every ray of the wave stays inside its LDS stack (almost always): two plain stores
                         if (qa) { stack_n[pos] = ea.w; stack_t[pos] = ta; pos++; }
                         if (qb) { stack_n[pos] = eb.w; stack_t[pos] = tb; }
@@ -1121,15 +1124,15 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #endif
                     {
                         if (qa) {
-                            if (pos < COOP_STACK) { stack_n[pos] = ea.w; stack_t[pos] = ta; }
-                            else if (pos < COOP_STACK + COOP_SPILL) { spill[pos - COOP_STACK] = make_uint2(ea.w, __float_as_uint(ta)); if (COUNT) atomicAdd(&counters->stack_spills, 1ull); }
+                            if (pos < QUAD_STACK) { stack_n[pos] = ea.w; stack_t[pos] = ta; }
+                            else if (pos < QUAD_STACK + COOP_SPILL) { spill[pos - QUAD_STACK] = make_uint2(ea.w, __float_as_uint(ta)); if (COUNT) atomicAdd(&counters->stack_spills, 1ull); }
                             pos++;
                         }
                         if (qb) {
-                            if (pos < COOP_STACK) { stack_n[pos] = eb.w; stack_t[pos] = tb; }
-                            else if (pos < COOP_STACK + COOP_SPILL) { spill[pos - COOP_STACK] = make_uint2(eb.w, __float_as_uint(tb)); if (COUNT) atomicAdd(&counters->stack_spills, 1ull); }
+                            if (pos < QUAD_STACK) { stack_n[pos] = eb.w; stack_t[pos] = tb; }
+                            else if (pos < QUAD_STACK + COOP_SPILL) { spill[pos - QUAD_STACK] = make_uint2(eb.w, __float_as_uint(tb)); if (COUNT) atomicAdd(&counters->stack_spills, 1ull); }
                         }
-                        if (sp > COOP_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
+                        if (sp > QUAD_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
                             triangle_index = HIT_RETRY;
                             active = false; npend = 0; cur = WIDE_NONE; sp = 0;
                         }
@@ -1173,6 +1176,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 npend -= take;
             }
         }
+
 
         // ---- retire finished rays
         if (has_ray && !active) {
@@ -1250,7 +1254,7 @@ k_raycast_pair(GeoView g, const float4 *rays, int first_photon, StepState *st,
     bool has_ray = false, active = false;
     int slot = 0;
     v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
-    v3 ra = mk3(0.f, 0.f, 0.f);
+    float rax = 0.f, ray_ = 0.f, raz = 0.f;
     f32x2 rbx = {0.f, 0.f}, rby = {0.f, 0.f}, rbz = {0.f, 0.f};
     uint32_t last_hit_w = WIDE_NONE;
     int triangle_index = -1;
@@ -1288,10 +1292,10 @@ k_raycast_pair(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     origin = mk3(r0.x, r0.y, r0.z);
                     direction = mk3(r1.x, r1.y, r1.z);
                     { const int lh = __float_as_int(r0.w); last_hit_w = lh >= 0 ? (0x80000000u | (uint32_t)lh) : WIDE_NONE; }
-                    ra = mk3(r2.x, r2.y, r2.z);
-                    rbx = (f32x2){r3.x - ra.x, r3.x + ra.x};
-                    rby = (f32x2){r3.y - ra.y, r3.y + ra.y};
-                    rbz = (f32x2){r3.z - ra.z, r3.z + ra.z};
+                    rax = r2.x; ray_ = r2.y; raz = r2.z;
+                    rbx = (f32x2){r3.x - rax, r3.x + rax};
+                    rby = (f32x2){r3.y - ray_, r3.y + ray_};
+                    rbz = (f32x2){r3.z - raz, r3.z + raz};
                     triangle_index = -1;
                     min_distance = -1.0f;
                     prune_t = cm_inff();
@@ -1311,7 +1315,7 @@ k_raycast_pair(GeoView g, const float4 *rays, int first_photon, StepState *st,
 
         // ---- node phase: every active pair visits one node per iteration
         more = !exhausted || loc_next < loc_end;
-        const int stop_at = more ? max(0, __popcll(__ballot(active && j == 0)) - PAIR_REFILL_MIN) : 0;
+        const int stop_at = more ? max(0, (int)__popcll(__ballot(active && j == 0)) - (int)PAIR_REFILL_MIN) : 0;
         do {
             __builtin_amdgcn_s_setprio(3);       // a wave about to fetch its next node goes before waves that compute
             if (!__any(sp > PAIR_STACK)) {
@@ -1337,10 +1341,10 @@ k_raycast_pair(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 __builtin_amdgcn_s_setprio(0);
                 if (COUNT && j == 0) cnt.nodes += 8;
                 float t0, t1, t2, t3, f0, f1, f2, f3;
-                box_interval_pk(ra, rbx, rby, rbz, e0, t0, f0);
-                box_interval_pk(ra, rbx, rby, rbz, e1, t1, f1);
-                box_interval_pk(ra, rbx, rby, rbz, e2, t2, f2);
-                box_interval_pk(ra, rbx, rby, rbz, e3, t3, f3);
+                box_interval_pk(rax, ray_, raz, rbx, rby, rbz, e0, t0, f0);
+                box_interval_pk(rax, ray_, raz, rbx, rby, rbz, e1, t1, f1);
+                box_interval_pk(rax, ray_, raz, rbx, rby, rbz, e2, t2, f2);
+                box_interval_pk(rax, ray_, raz, rbx, rby, rbz, e3, t3, f3);
                 // intersect_node (mesh.h:16-34) with prune_t = +inf until something is hit
                 const bool p0 = (e0.w != WIDE_NONE) & !(t0 > f0) & !(t0 > prune_t);
                 const bool p1 = (e1.w != WIDE_NONE) & !(t1 > f1) & !(t1 > prune_t);
@@ -2354,7 +2358,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     const bool have_wide = geom->view.wnodes != nullptr;
     const bool pair = ctx->wide_walk == CHROMA_WALK_PAIR && have_wide && geom->wide_stack_need <= PAIR_STACK + COOP_SPILL;
     const bool quad = !pair && (ctx->wide_walk == CHROMA_WALK_QUAD || ctx->wide_walk == CHROMA_WALK_PAIR) && have_wide &&
-                      geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
+                      geom->wide_stack_need <= QUAD_STACK + COOP_SPILL;
     const bool coop = !pair && !quad && (ctx->wide_walk == CHROMA_WALK_COOP || ctx->wide_walk == CHROMA_WALK_QUAD) && have_wide &&
                       geom->wide_stack_need <= COOP_STACK + COOP_SPILL;
     const bool wide = !pair && !coop && !quad && ctx->wide_walk != CHROMA_WALK_REFERENCE && have_wide && geom->wide_stack_need <= WIDE_STACK + WIDE_SPILL;

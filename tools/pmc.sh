@@ -15,7 +15,9 @@ for grp in \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" \
   "GRBM_GUI_ACTIVE" ; do
   i=$((i+1))
-  timeout -k 5 120 rocprofv3 --pmc $grp --output-format csv -d $out/pass$i -- "$@" > $out/pass$i.stdout 2> $out/pass$i.stderr
+  if [ -n "${PMC_GROUPS:-}" ] && ! echo " $PMC_GROUPS " | grep -q " $i "; then continue; fi
+  timeout -k 5 ${PMC_TIMEOUT:-120} rocprofv3 --pmc $grp --output-format csv -d $out/pass$i -- "$@" > $out/pass$i.stdout 2> $out/pass$i.stderr
   echo "pass $i rc=$? : $grp"
 done
 python tools/pmc_summary.py $out
+# (PMC_GROUPS="1 2" restricts the passes: see the loop above)
