@@ -1723,16 +1723,34 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
     if (nretry == 0) return;
     LaneCounters cnt = {0, 0, 0, 0};
     const int stride = gridDim.x * PROP_BLOCK;
-    for (int k = blockIdx.x * PROP_BLOCK + threadIdx.x; k < nretry; k += stride) {      // lanes are independent here
-        const int slot = (int)retry_list[k];
-        const float4 *r = rays + 4 * (size_t)slot;
-        const float4 r0 = r[0], r1 = r[1];
-        v3 position = mk3(r0.x, r0.y, r0.z), direction = mk3(r1.x, r1.y, r1.z);          // (normalised by k_ray_setup)
-        int last_hit = __float_as_int(r0.w);
+    // (the loop bound is wave-uniform: intersect_mesh_dev votes across the wave)
+    for (int k0 = blockIdx.x * PROP_BLOCK; k0 < nretry; k0 += stride) {
+        const int k = k0 + (int)threadIdx.x;
+        bool walk = false;
+        int slot = 0, last_hit = -1;
+        v3 position = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
+        if (k < nretry) {
+            slot = (int)retry_list[k];
+            const float4 *r = rays + 4 * (size_t)slot;
+            const float4 r0 = r[0], r1 = r[1];
+            position = mk3(r0.x, r0.y, r0.z); direction = mk3(r1.x, r1.y, r1.z);         // (normalised by k_ray_setup)
+            last_hit = __float_as_int(r0.w);
+            // a slot k_physics listed because the cheap test could not vouch for the fast walk's winner still holds
+            // that winner: the exact question first (the leaf box by the reference's rule, the reference's slab
+            // test); only a winner the reference may really miss is walked again
+            const int rec = hit_triangle[slot];
+            walk = true;
+            if (rec >= 0) {
+                const float4 *t = g.tri + TRI_STRIDE * (size_t)rec;
+                walk = !record_hit_is_exactly_regular(g, t[0], t[1], t[2], position, direction, hit_distance[slot]);
+            }
+        }
         float dist;
-        int found = intersect_mesh_dev<STACK_LDS, PROP_BLOCK, COUNT>(g, position, direction, dist, last_hit, s_lds + threadIdx.x, cnt, true);
-        hit_triangle[slot] = found;
-        hit_distance[slot] = dist;
+        int found = intersect_mesh_dev<STACK_LDS, PROP_BLOCK, COUNT>(g, position, direction, dist, last_hit, s_lds + threadIdx.x, cnt, walk);
+        if (walk) {
+            hit_triangle[slot] = found;
+            hit_distance[slot] = dist;
+        }
     }
     unsigned long long ov = wave_sum_u64(cnt.overflows);
     if (COUNT) {
@@ -1750,7 +1768,11 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
 #ifndef PHYS_WAVES_PER_EU
 #define PHYS_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(PHYS_BLOCK) __attribute__((amdgpu_waves_per_eu(PHYS_WAVES_PER_EU))) void
+#ifndef PHYS_PLAIN_WAVES_PER_EU
+#define PHYS_PLAIN_WAVES_PER_EU 4
+#endif
+template <bool FULL>
+__global__ __launch_bounds__(PHYS_BLOCK) __attribute__((amdgpu_waves_per_eu(FULL ? PHYS_WAVES_PER_EU : PHYS_PLAIN_WAVES_PER_EU))) void
 k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32_t *output_queue, float4 *work_out,
           const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base,
           int use_weights, int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters)
@@ -1791,8 +1813,8 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
             if (!fixup && tri >= 0) {
                 // is the fast walk's winner one the reference is sure to find too?
                 const float4 *t = g.tri + TRI_STRIDE * (size_t)tri;
-                if (!record_hit_is_regular(g, t[0], t[1], t[2], p.position, p.direction, hit_dist)) {
-                    retry_list[atomicAdd(&st->retry, 1u)] = (uint32_t)slot;
+                if (!record_hit_is_plainly_regular(g, t[0], t[1], t[2], p.position, p.direction, hit_dist)) {
+                    retry_list[atomicAdd(&st->retry, 1u)] = (uint32_t)slot;       // (k_raycast_retry asks the exact question)
                     tri = HIT_RETRY;
                 }
             }
@@ -1815,7 +1837,7 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
             } else {
                 State s;
                 apply_hit_dev(s, p, g, tri, hit_dist);
-                if (tri != -1) step_after_hit(p, s, rng, g, use_weights != 0, scatter_first);
+                if (tri != -1) step_after_hit<FULL>(p, s, rng, g, use_weights != 0, scatter_first);
                 // (a photon scattered or absorbed in the bulk forgets the triangle, photon.h:232,262,283)
                 last_hit_record = (p.last_hit_triangle < 0) ? -1 : tri;
             }
@@ -2412,18 +2434,29 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     // physics for every slot whose hit is regular; then the strict walk and the physics of the rest
     unsigned pblocks = (unsigned)std::min<long long>((n_upper + PHYS_BLOCK - 1) / PHYS_BLOCK, (long long)ctx->physics_blocks);
     DeviceCounters *pc = ctx->counting ? ctx->d_counters : nullptr;
-    hipLaunchKernelGGL(k_physics, dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
-                       ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                       ctx->retry_list, 0, pc);
+    const bool plain = geom->view.plain_optics != 0;      // (no re-emitting component, default surface model only)
+    if (plain)
+        hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
+                           ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
+                           ctx->retry_list, 0, pc);
+    else
+        hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
+                           ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
+                           ctx->retry_list, 0, pc);
     if (ctx->counting)
         hipLaunchKernelGGL((k_raycast_retry<true>), dim3(256), block, 0, ctx->stream, geom->view, ctx->rays, st,
                            ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
     else
         hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, ctx->rays, st,
                            ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
-    hipLaunchKernelGGL(k_physics, dim3(std::min(pblocks, 64u)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
-                       work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
-                       scatter_first, ctx->retry_list, 1, pc);
+    if (plain)
+        hipLaunchKernelGGL((k_physics<false>), dim3(std::min(pblocks, 64u)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
+                           work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
+                           scatter_first, ctx->retry_list, 1, pc);
+    else
+        hipLaunchKernelGGL((k_physics<true>), dim3(std::min(pblocks, 64u)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
+                           work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
+                           scatter_first, ctx->retry_list, 1, pc);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
@@ -2991,6 +3024,10 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     v.wavelength_n = d->wavelength_n; v.wavelength_start = d->wavelength_start; v.wavelength_step = d->wavelength_step;
     v.time_n = d->time_n; v.time_start = d->time_start; v.time_step = d->time_step;
     v.nnodes = d->nnodes; v.ntriangles = d->ntriangles; v.nsolids = d->nsolids; v.nchannels = d->nchannels;
+    v.plain_optics = 1u;
+    for (uint32_t m = 0; m < d->nmaterials; m++) if (d->mat_num_comp[m]) v.plain_optics = 0u;
+    for (uint32_t k = 0; k < d->nsurfaces; k++) if (d->surf_model[k] != CHROMA_SURFACE_DEFAULT) v.plain_optics = 0u;
+    if (getenv("CHROMA_FULL_PHYSICS")) v.plain_optics = 0u;          // (A/B: the all-models kernel on a plain geometry)
 
     phase("mesh arrays + tables");
     g->stack_need = compute_stack_need(d->nodes, d->nnodes);

@@ -81,6 +81,7 @@ struct GeoView {
     uint32_t wavelength_n; float wavelength_start, wavelength_step;
     uint32_t time_n;       float time_start, time_step;
     uint32_t nnodes, ntriangles, nsolids, nchannels, nwide;
+    uint32_t plain_optics;           // no re-emitting material component, every surface of the default model
 };
 
 struct PhotonView {   // device pointers of chroma_photon_arrays

@@ -43,7 +43,7 @@ __device__ inline float interp_property(const GeoView &g, float x, const float *
     uint32_t n = g.wavelength_n;
     if (x < start) return fp[0];
     if (x > (start + (float)(n - 1) * step)) return fp[n - 1];
-    int jl = (int)((x - start) / step);
+    int jl = cm_f2i((x - start) / step);
     int ju = (jl + 1 < (int)n) ? jl + 1 : (int)n - 1;
     return fp[jl] + (x - (start + (float)jl * step)) * (fp[ju] - fp[jl]) / step;
 }
@@ -170,7 +170,8 @@ __device__ inline bool reference_tests_leaf(const GeoView &g, uint32_t bx, uint3
 // world coordinate): the slab test passes.  Only a hit within the margin of a maximum face (~1e-3 of
 // the hits) takes the exact route: the leaf box by the reference's rule, then the test above.
 __device__ inline void leaf_words(const GeoView &g, v3 v0, v3 v1, v3 v2, uint32_t &bx, uint32_t &by, uint32_t &bz);
-__device__ inline bool record_hit_is_regular(const GeoView &g, float4 a, float4 b, float4 c, v3 origin, v3 direction, float t)
+// the cheap sufficient part: true = the reference is sure to test this triangle
+__device__ inline bool record_hit_is_plainly_regular(const GeoView &g, float4 a, float4 b, float4 c, v3 origin, v3 direction, float t)
 {
     const float m = 2.0f * g.suspect_margin, half = 0.5f * g.world_scale;
     float px = origin.x + t * direction.x, py = origin.y + t * direction.y, pz = origin.z + t * direction.z;
@@ -181,10 +182,18 @@ __device__ inline bool record_hit_is_regular(const GeoView &g, float4 a, float4 
     bool low_ok = px >= lx - half && py >= ly - half && pz >= lz - half &&
                   lx >= g.world_origin[0] + g.world_scale && ly >= g.world_origin[1] + g.world_scale &&
                   lz >= g.world_origin[2] + g.world_scale;
-    if (low_ok && px <= hx - m && py <= hy - m && pz <= hz - m) return true;
+    return low_ok && px <= hx - m && py <= hy - m && pz <= hz - m;
+}
+// the exact route: the leaf box by the reference's rule, then the reference's slab test
+__device__ inline bool record_hit_is_exactly_regular(const GeoView &g, float4 a, float4 b, float4 c, v3 origin, v3 direction, float t)
+{
     uint32_t bx, by, bz;
     leaf_words(g, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, bz);
     return reference_tests_leaf(g, bx, by, bz, origin, direction, t);
+}
+__device__ inline bool record_hit_is_regular(const GeoView &g, float4 a, float4 b, float4 c, v3 origin, v3 direction, float t)
+{
+    return record_hit_is_plainly_regular(g, a, b, c, origin, direction, t) || record_hit_is_exactly_regular(g, a, b, c, origin, direction, t);
 }
 
 // the leaf box of a triangle by the reference's rule (cuda/bvh.cu:149-203: truncate, one quantum down,
@@ -519,6 +528,11 @@ __device__ inline void rayleigh_scatter(Photon &p, cm_rng &rng)
 }
 
 // propagate_to_boundary (photon.h:193-308)
+// FULL = false: the build for geometries whose materials have no re-emitting components and whose surfaces
+// all use the default model (GeoView::plain_optics, decided once at chroma_geometry_create): the bulk
+// re-emission, thin-film, wavelength-shifter and dichroic code is not compiled in, which halves the
+// registers of the per-step physics kernel for the detectors of configs C1-C4.
+template <bool FULL>
 __device__ inline int propagate_to_boundary(Photon &p, State &s, cm_rng &rng, const GeoView &g,
                                             bool use_weights, int scatter_first)
 {
@@ -559,7 +573,7 @@ __device__ inline int propagate_to_boundary(Photon &p, State &s, cm_rng &rng, co
             p.time += absorption_distance / (CM_SPEED_OF_LIGHT / s.refractive_index1);
             p.position = p.position + absorption_distance * p.direction;
 
-            uint32_t num_comp = g.mat_num_comp[s.material1];
+            uint32_t num_comp = FULL ? g.mat_num_comp[s.material1] : 0u;
             if (num_comp == 0) {
                 p.last_hit_triangle = -1;
                 p.history |= CHROMA_BULK_ABSORB;
@@ -894,7 +908,7 @@ __device__ inline int propagate_at_dichroic(Photon &p, State &s, cm_rng &rng, co
     uint32_t nangles = g.dichroic_nangles[di];
     uint32_t base = g.dichroic_offset[di];
     float idx = interp_idx(incident_angle, (int)nangles, g.dichroic_angles + base);
-    uint32_t iidx = (uint32_t)(int)idx;
+    uint32_t iidx = (uint32_t)cm_f2i(idx);
     uint32_t iidx_hi = iidx < nangles - 2 ? iidx + 1 : iidx;
     float reflect_prob_low = interp_property(g, p.wavelength, row(g.dichroic_reflect, g, (int)(base + iidx)));
     float reflect_prob_high = interp_property(g, p.wavelength, row(g.dichroic_reflect, g, (int)(base + iidx_hi)));
@@ -918,16 +932,19 @@ __device__ inline int propagate_at_dichroic(Photon &p, State &s, cm_rng &rng, co
 }
 
 // propagate_at_surface (photon.h:672-733)
+template <bool FULL>
 __device__ inline int propagate_at_surface(Photon &p, State &s, cm_rng &rng, const GeoView &g, bool use_weights)
 {
     int si = s.surface_index;
-    uint32_t model = g.surf_info[si].model;
-    if (model == CHROMA_SURFACE_COMPLEX)
-        return propagate_complex(p, s, rng, g, si, use_weights);
-    else if (model == CHROMA_SURFACE_WLS)
-        return propagate_at_wls(p, s, rng, g, si, use_weights);
-    else if (model == CHROMA_SURFACE_DICHROIC)
-        return propagate_at_dichroic(p, s, rng, g, si);
+    if (FULL) {
+        uint32_t model = g.surf_info[si].model;
+        if (model == CHROMA_SURFACE_COMPLEX)
+            return propagate_complex(p, s, rng, g, si, use_weights);
+        else if (model == CHROMA_SURFACE_WLS)
+            return propagate_at_wls(p, s, rng, g, si, use_weights);
+        else if (model == CHROMA_SURFACE_DICHROIC)
+            return propagate_at_dichroic(p, s, rng, g, si);
+    }
 
     float detect = interp_property(g, p.wavelength, row(g.surf_detect, g, si));
     float absorb = interp_property(g, p.wavelength, row(g.surf_absorb, g, si));
@@ -965,13 +982,14 @@ __device__ inline int propagate_at_surface(Photon &p, State &s, cm_rng &rng, con
 
 // The part of one loop iteration of propagate.cu:264-301 that follows fill_state.
 // Returns false when the photon's loop ends (BREAK), true when it goes on.
+template <bool FULL = true>
 __device__ inline bool step_after_hit(Photon &p, State &s, cm_rng &rng, const GeoView &g, bool use_weights, int scatter_first)
 {
-    int command = propagate_to_boundary(p, s, rng, g, use_weights, scatter_first);
+    int command = propagate_to_boundary<FULL>(p, s, rng, g, use_weights, scatter_first);
     if (command == CMD_BREAK) return false;
     if (command == CMD_CONTINUE) return true;
     if (s.surface_index != -1) {
-        command = propagate_at_surface(p, s, rng, g, use_weights);
+        command = propagate_at_surface<FULL>(p, s, rng, g, use_weights);
         if (command == CMD_BREAK) return false;
         if (command == CMD_CONTINUE) return true;
     }

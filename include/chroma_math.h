@@ -48,6 +48,18 @@ CM_FN float cm_fabsf(float x) { return cm_u2f(cm_f2u(x) & 0x7fffffffu); }
 CM_FN float cm_fminf(float a, float b) { if (cm_isnan(a)) return b; if (cm_isnan(b)) return a; return (b < a) ? b : a; }
 CM_FN float cm_fmaxf(float a, float b) { if (cm_isnan(a)) return b; if (cm_isnan(b)) return a; return (b > a) ? b : a; }
 
+/* float -> int as the GPUs do it (CUDA's cast and v_cvt_i32_f32 alike): toward zero, NaN -> 0, saturating.
+ * A C cast of NaN or of an out-of-range value is undefined (x86 gives INT_MIN); the table lookups of the path
+ * index with such casts, and a photon whose wavelength has become NaN must read the same table entry on
+ * both sides instead of crashing the CPU oracle. */
+CM_FN int cm_f2i(float x)
+{
+    if (cm_isnan(x)) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return -2147483647 - 1;
+    return (int)x;
+}
+
 CM_FN float cm_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 CM_FN float cm_sqrtf(float x) { return __builtin_sqrtf(x); }
 CM_FN float cm_roundf(float x) { return __builtin_roundf(x); }   /* half away from zero, exact */

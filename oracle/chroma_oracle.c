@@ -154,7 +154,7 @@ static inline float interp_property(Geo *g, float x, const float *fp)
     uint32_t n = g->wavelength_n;
     if (x < start) return fp[0];
     if (x > (start + (float)(n - 1) * step)) return fp[n - 1];
-    int jl = (int)((x - start) / step);
+    int jl = cm_f2i((x - start) / step);
     int ju = (jl + 1 < (int)n) ? jl + 1 : (int)n - 1;
     return fp[jl] + (x - (start + (float)jl * step)) * (fp[ju] - fp[jl]) / step;
 }
@@ -804,7 +804,7 @@ static int propagate_at_dichroic(Photon *p, State *s, cm_rng *rng, Geo *g, int s
     uint32_t nangles = g->dichroic_nangles[di];
     uint32_t base = g->dichroic_offset[di];
     float idx = interp_idx(incident_angle, (int)nangles, g->dichroic_angles + base);
-    uint32_t iidx = (uint32_t)(int)idx;
+    uint32_t iidx = (uint32_t)cm_f2i(idx);
     uint32_t iidx_hi = iidx < nangles - 2 ? iidx + 1 : iidx;
     float reflect_prob_low = interp_property(g, p->wavelength, mat_row(g->dichroic_reflect, g, (int)(base + iidx)));
     float reflect_prob_high = interp_property(g, p->wavelength, mat_row(g->dichroic_reflect, g, (int)(base + iidx_hi)));
