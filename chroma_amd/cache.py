@@ -22,11 +22,67 @@ def default_cache_dir():
     return os.path.join(os.path.expanduser('~'), '.chroma_amd')
 
 
+class GeometryNotFoundError(Exception):
+    pass
+
+
 class Cache(object):
     def __init__(self, cache_dir=None):
         self.cache_dir = default_cache_dir() if cache_dir is None else cache_dir
         self.bvh_dir = os.path.join(self.cache_dir, 'bvh')
+        self.geo_dir = os.path.join(self.cache_dir, 'geo')
         os.makedirs(self.bvh_dir, exist_ok=True)
+        os.makedirs(self.geo_dir, exist_ok=True)
+
+    # ---- named geometries (chroma/cache.py:90-176): pickles of flattened Geometry objects WITHOUT their BVH, which
+    # is looked up by mesh hash.  A pickle runs code when loaded: the cache directory is the user's own, as in the
+    # reference; never point cache_dir at files from somebody else.
+    def get_geometry_filename(self, name):
+        if not name or not all(c.isalnum() or c in '._-' for c in name) or name.startswith('.'):
+            raise ValueError('invalid geometry name %r' % name)
+        return os.path.join(self.geo_dir, name)
+
+    def list_geometry(self):
+        return sorted(n for n in os.listdir(self.geo_dir) if n != 'default')
+
+    def save_geometry(self, name, geometry):
+        import copy
+        import pickle
+        g = copy.copy(geometry)
+        g.bvh = None
+        path = self.get_geometry_filename(name)
+        with open(path + '.tmp', 'wb') as f:
+            pickle.dump(g, f, pickle.HIGHEST_PROTOCOL)
+        os.replace(path + '.tmp', path)
+        return path
+
+    def load_geometry(self, name):
+        import pickle
+        path = self.get_geometry_filename(name)
+        if not os.path.exists(path):
+            raise GeometryNotFoundError(name)
+        with open(path, 'rb') as f:
+            return pickle.load(f)
+
+    def remove_geometry(self, name):
+        path = self.get_geometry_filename(name)
+        if not os.path.exists(path):
+            raise GeometryNotFoundError(name)
+        os.remove(path)
+
+    def set_default_geometry(self, name):
+        if not os.path.exists(self.get_geometry_filename(name)):
+            raise GeometryNotFoundError(name)
+        link = os.path.join(self.geo_dir, 'default')
+        if os.path.lexists(link):
+            os.remove(link)
+        os.symlink(name, link)
+
+    def load_default_geometry(self):
+        link = os.path.join(self.geo_dir, 'default')
+        if not os.path.exists(link):
+            raise GeometryNotFoundError('default')
+        return self.load_geometry(os.path.basename(os.path.realpath(link)))
 
     def get_bvh_path(self, mesh_hash, name='default'):
         if not name or not all(c.isalnum() or c in '._-' for c in name) or name.startswith('.'):

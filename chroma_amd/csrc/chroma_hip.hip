@@ -224,13 +224,17 @@ k_propagate(GeoView g, PhotonView pv, int first_photon, int nthreads, const uint
 // (the tail of its input queue), whether its launch re-normalises (the reference's launch policy,
 // chroma/gpu/photon.py:225-252) and the ray-cast work counters live in StepState (top of this file),
 // written by k_step_begin at the head of every step and read by the step's kernels.
-__global__ void k_step_begin(const uint32_t *in_queue, uint32_t *out_queue, StepState *st, uint32_t few)
+// `first_n` (first step of a call only, else 0): the size of the caller's arrays.  The reference decides its
+// FIRST launch on pos.size, photons that are already terminal included (gpu/photon.py:207,227), and every
+// later one on the survivor count; a batch that is mostly terminal already therefore still gets a
+// one-step launch first and is re-normalised again by the launch after it.
+__global__ void k_step_begin(const uint32_t *in_queue, uint32_t *out_queue, StepState *st, uint32_t few, uint32_t first_n)
 {
     const uint32_t n = in_queue[0] - 1u;
     st->n = n;
     uint32_t renorm = 1u;
     if (st->in_tail) renorm = 0u;
-    else if (n < few) st->in_tail = 1u;
+    else if ((first_n ? first_n : n) < few) st->in_tail = 1u;
     st->renorm = renorm;
     if (renorm && n) st->launches++;
     st->work = 0u;
@@ -2371,7 +2375,7 @@ static size_t spill_entries(const chroma_ctx *ctx)
 // [3] ray-cast kernel start, [1] its end, [2] step end.
 static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, long long n_upper, const uint32_t *in_q,
                              uint32_t *out_q, const float4 *work_in, float4 *work_out, chroma_rng rng, int use_weights,
-                             int scatter_first, hipEvent_t *ev = nullptr)
+                             int scatter_first, hipEvent_t *ev = nullptr, uint32_t first_n = 0)
 {
     if (n_upper <= 0) return CHROMA_OK;
     uint32_t need = geom->stack_need;
@@ -2402,7 +2406,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     StepState *st = ctx->d_step;
     // (with weights the reference runs ALL steps in one launch: every count is "few")
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st,
-                       use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8));
+                       use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8), first_n);
     if (ev) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
     {
         unsigned sblocks = (unsigned)std::min<long long>((n_upper + 255) / 256, (long long)ctx->physics_blocks * 4);
@@ -2466,7 +2470,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
 // *done when the geometry has a wide tree the kernel can walk; otherwise leaves *done false.
 static int launch_tail(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, long long n_upper, const uint32_t *in_q,
                        uint32_t *out_q, const float4 *work_in, chroma_rng rng, int nsteps, int use_weights, int scatter_first,
-                       hipEvent_t *ev, bool *done)
+                       hipEvent_t *ev, bool *done, uint32_t first_n = 0)
 {
     *done = false;
     if (!geom->view.wnodes || geom->wide_stack_need > COOP_STACK + COOP_SPILL || geom->stack_need > STACK_LDS + STACK_SCRATCH)
@@ -2479,7 +2483,7 @@ static int launch_tail(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, lo
     if ((long long)waves * 8 < n_upper) return CHROMA_OK;          // (cannot happen below 8192 photons)
     StepState *st = ctx->d_step;
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st,
-                       use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8));
+                       use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8), first_n);
     if (ev) { HIP_TRY(hipEventRecord(ev[0], ctx->stream)); HIP_TRY(hipEventRecord(ev[1], ctx->stream)); }
     if (ctx->counting)
         hipLaunchKernelGGL((k_tail_coop<true>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in,
@@ -3378,7 +3382,8 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                 // the reference's last launch: all remaining steps at once, 8 lanes per photon
                 bool launched = false;
                 rc = launch_tail(ctx, geom, pv, n_upper, in_q, out_q, work_in, rng, max_steps - step, use_weights,
-                                 step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 4 * step : nullptr, &launched);
+                                 step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 4 * step : nullptr, &launched,
+                                 step == 0 ? (uint32_t)nphotons : 0u);
                 if (rc) return rc;
                 if (launched) {
                     if (time_kernels) { tail_step = step; steps_timed = step + 1; }
@@ -3388,7 +3393,8 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                 }
             }
             rc = launch_split_step(ctx, geom, pv, n_upper, in_q, out_q, work_in, work_out, rng, use_weights,
-                                   step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 4 * step : nullptr);
+                                   step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 4 * step : nullptr,
+                                   step == 0 ? (uint32_t)nphotons : 0u);
             if (rc) return rc;
             if (time_kernels) steps_timed = step + 1;
             step++;

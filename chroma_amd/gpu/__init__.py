@@ -6,3 +6,4 @@ from chroma_amd.gpu.geometry import GPUGeometry, pack_geometry
 from chroma_amd.gpu.detector import GPUDetector
 from chroma_amd.gpu.photon import GPUPhotons, GPUPhotonsSlice, generate_bomb
 from chroma_amd.gpu.daq import GPUDaq, GPUChannels
+from chroma_amd.gpu.funcs import get_cu_module, GPUFuncs

@@ -7,6 +7,8 @@ reference the cache is OFF by default, because a build takes seconds.
 ``load_geometry_from_string`` resolves the "@module.function" form of chroma/loader.py:90-112.
 """
 import importlib
+import os
+import sys
 
 from chroma_amd.bvh import make_recursive_grid_bvh
 from chroma_amd.log import logger
@@ -61,12 +63,31 @@ def create_geometry_from_obj(obj, bvh_name="default", auto_build_bvh=True, read_
 
 def load_geometry_from_string(geometry_str, auto_build_bvh=True, read_bvh_cache=True, update_bvh_cache=True,
                               cache_dir=None, cuda_device=None):
-    """"@module.function[:bvh_name]" -> flattened geometry with BVH (chroma/loader.py:90-112).  The
-    function is called without arguments and must return a Geometry, Solid or Mesh."""
-    if not geometry_str.startswith('@'):
-        raise ValueError('only the "@module.function" form is supported (no STL files or named cache entries)')
-    name, _, bvh_name = geometry_str[1:].partition(':')
-    module_name, _, function_name = name.rpartition('.')
-    obj = getattr(importlib.import_module(module_name), function_name)()
-    return create_geometry_from_obj(obj, bvh_name=bvh_name or 'default', auto_build_bvh=auto_build_bvh,
-                                    read_bvh_cache=read_bvh_cache, update_bvh_cache=update_bvh_cache, cache_dir=cache_dir)
+    """A flattened geometry with its BVH from one of the reference's geometry strings (chroma/loader.py:13-137):
+    ``"file.stl[.bz2][:bvh]"`` (a mesh on disk, vacuum inside and out), ``"@module.function[:bvh]"`` (called
+    without arguments; returns a Geometry, Solid or Mesh; the current directory is importable too),
+    ``"name[:bvh]"`` (a geometry saved in the cache under that name) and ``""`` (the cache's default geometry).
+    ``cuda_device`` is accepted for compatibility: the BVH is built on the host."""
+    geometry_id, _, bvh_name = geometry_str.partition(':')
+    bvh_name = bvh_name or 'default'
+    kw = dict(bvh_name=bvh_name, auto_build_bvh=auto_build_bvh, read_bvh_cache=read_bvh_cache,
+              update_bvh_cache=update_bvh_cache, cache_dir=cache_dir)
+    if geometry_id.startswith('@'):
+        module_name, _, function_name = geometry_id[1:].rpartition('.')
+        saved = list(sys.path)
+        try:
+            sys.path.append('.')
+            module = importlib.import_module(module_name)
+        finally:
+            sys.path[:] = saved
+        return create_geometry_from_obj(getattr(module, function_name)(), **kw)
+    if os.path.exists(geometry_id) and geometry_id.lower().endswith(('.stl', '.bz2')):
+        from chroma_amd.stl import mesh_from_stl
+        from chroma_amd.geometry import Geometry, Solid, vacuum
+        geometry = Geometry()
+        geometry.add_solid(Solid(mesh_from_stl(geometry_id), vacuum, vacuum, color=0x33ffffff))
+        return create_geometry_from_obj(geometry, **kw)
+    from chroma_amd.cache import Cache
+    cache = Cache(cache_dir)
+    geometry = cache.load_default_geometry() if geometry_id == '' else cache.load_geometry(geometry_id)
+    return create_geometry_from_obj(geometry, **kw)

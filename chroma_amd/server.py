@@ -136,12 +136,17 @@ class RatServer(object):
 
 
 def main_server(argv=None):
-    """bin/chroma-server <detector> [--address tcp://*:5024]"""
+    """bin/chroma-server <detector> [--address tcp://127.0.0.1:5024]
+
+    The request/reply payloads are PICKLES (recv_pyobj / send_pyobj, as bin/chroma-server:24-38): whoever can reach
+    the socket can run code in this process.  The default therefore listens on the loopback interface only (the
+    reference binds tcp://*:5024); pass --address to serve a trusted network, or use chroma-server-rat, whose
+    packed binary format carries numbers only."""
     import argparse
     from .loader import load_geometry_from_string
     ap = argparse.ArgumentParser(description='Serves a chroma geometry on a ZeroMQ socket: pickled Photons in, final Photons out')
     ap.add_argument('detector', help='a chroma geometry identifier string')
-    ap.add_argument('--address', default='tcp://*:5024')
+    ap.add_argument('--address', default='tcp://127.0.0.1:5024')
     args = ap.parse_args(argv)
     ChromaServer(args.address, load_geometry_from_string(args.detector)).serve_forever()
 

@@ -239,6 +239,18 @@ def test_tracking_mode(gpu, oracle_mod):
     assert len(ids) == len(steps) and len(ids[0]) == 300
     assert all(len(i) == len(s) for i, s in zip(ids, steps))
     assert len(ids[-1]) <= len(ids[0])
+    # step by step against the oracle driven the same way (one launch per step, chroma/gpu/photon.py:218-238):
+    # entry k holds the photons that ENTERED step k, in queue order, as they are AFTER it
+    from chroma_amd.gpu.geometry import pack_geometry
+    pk = pack_geometry(geo)
+    cur, ctr = ph, None
+    assert_bit_exact(steps[0], cur[ids[0]], 'track, before the first step')
+    for k in range(1, len(ids)):
+        alive_before = np.flatnonzero((cur.flags & event.TERMINAL_MASK) == 0) if k > 1 else np.arange(len(ph))
+        assert sorted(ids[k].tolist()) == alive_before.tolist(), 'track: step %d did not get exactly the live photons' % k
+        cur, ctr, _ = oracle_mod.propagate(pk, cur, seed=2, max_steps=1, rng_counters=ctr)
+        assert_bit_exact(steps[k], cur[ids[k]], 'track, after step %d' % k)
+    assert_bit_exact(gp.get(), cur, 'track, final arrays')
 
 
 def test_simulation_api_ports_of_reference_tests(gpu):
@@ -576,3 +588,74 @@ def pack_geometry_cached(geometry):
     if id(geometry) not in _packed_cache:
         _packed_cache[id(geometry)] = pack_geometry(geometry)
     return _packed_cache[id(geometry)]
+
+
+def test_first_launch_is_decided_on_the_array_size(gpu, oracle_mod, tiny_geometry):
+    """A batch of 20 000 photons of which only 5 000 are still alive: the reference decides its FIRST launch on
+    pos.size (terminal photons included: one step, chroma/gpu/photon.py:207,227) and the next one on the
+    survivors (< 8192: all remaining steps), and every launch re-normalises dir/pol on load
+    (propagate.cu:248,250) -- two re-normalisations, visible in the last bits.  Per-step launches, the fused
+    tail and the reference's own launch shape agree with the oracle's restatement of that loop."""
+    ph = bomb(20000, 23)
+    ph.dir *= np.linspace(0.7, 1.3, len(ph))[:, None]          # not normalised: every re-normalisation shows
+    ph.flags[5000:] = event.BULK_ABSORB
+    for tail in ('coop', 'split', 'fused'):
+        gpu.get_context().set_tail(tail)
+        try:
+            gg, gp, got, want, counters, stats, ostats = run_both(gpu, oracle_mod, tiny_geometry, ph, max_steps=20)
+        finally:
+            gpu.get_context().set_tail('coop')
+        assert_bit_exact(got, want, 'mostly terminal batch, %s tail' % tail)
+        assert np.array_equal(gp.rng_counters.get(), counters)
+        assert stats['launches'] == ostats['launches'] >= 2, (tail, stats['launches'], ostats['launches'])
+    assert (got.flags[5000:] == event.BULK_ABSORB).all() and np.array_equal(got.dir[5000:], ph.dir[5000:].astype(np.float32))
+
+
+def test_kernels_by_name_and_the_chroma_import_name(oracle_mod, tiny_geometry):
+    """Host code written against the reference: ``import chroma``, kernels looked up by name through
+    get_cu_module / GPUFuncs (chroma/gpu/tools.py:14-54) and called with the reference kernels' positional
+    arguments (chroma/gpu/photon.py:58-63,232-241).  Same photons as GPUPhotons.propagate step by step."""
+    import chroma
+    from chroma import gpu as cgpu
+    from chroma.gpu import get_cu_module, GPUFuncs, cuda_options, GPUPhotons, to_float3
+    from chroma.gpu.tools import GPUArray
+    import chroma_amd.gpu
+    assert cgpu is chroma_amd.gpu and chroma.event.Photons is Photons
+    ctx = cgpu.create_cuda_context(0)
+    try:
+        gg = cgpu.GPUDetector(tiny_geometry)
+        funcs = GPUFuncs(get_cu_module('propagate.cu', options=cuda_options))
+        ph = oracle_mod.generate_bomb(3000, seed=4)
+        n = len(ph)
+        f3 = lambda a: cgpu.to_gpu(to_float3(a), ctx)
+        pos, dir_, pol = f3(ph.pos), f3(ph.dir), f3(ph.pol)
+        wl, t, w = (cgpu.to_gpu(ph.wavelengths.astype(np.float32), ctx), cgpu.to_gpu(ph.t.astype(np.float32), ctx),
+                    cgpu.to_gpu(ph.weights.astype(np.float32), ctx))
+        flags, last, evidx = (cgpu.to_gpu(ph.flags.astype(np.uint32), ctx), cgpu.to_gpu(ph.last_hit_triangles.astype(np.int32), ctx),
+                              cgpu.to_gpu(ph.evidx.astype(np.uint32), ctx))
+        rng_states = cgpu.get_rng_states(64 * 1024, seed=6)
+        # the reference's own launch loop (gpu/photon.py:225-252) for a batch below 8192: one launch, all steps
+        in_q = cgpu.to_gpu(np.arange(n + 1, dtype=np.uint32), ctx)          # slot 0 unused, then ids 0..n-1 shifted by the [1:] view
+        in_q.set(np.r_[0, np.arange(n)].astype(np.uint32))
+        out_q = cgpu.to_gpu(np.r_[1, np.zeros(n)].astype(np.uint32), ctx)
+        funcs.propagate(np.int32(0), np.int32(n), in_q[1:], out_q, rng_states, pos, dir_, wl, pol, t, flags, last, w, evidx,
+                        np.int32(20), np.int32(0), np.int32(0), gg.gpudata, block=(64, 1, 1), grid=(n // 64 + 1, 1))
+        want, _, _ = oracle_mod.propagate(pack_geometry_cached(tiny_geometry), ph, seed=6, max_steps=20)
+        assert np.array_equal(flags.get(), want.flags) and np.array_equal(last.get(), want.last_hit_triangles)
+        assert np.array_equal(t.get().view(np.uint32), want.t.view(np.uint32))
+        # count_photons adds to its counter, like the kernel
+        counter = cgpu.to_gpu(np.array([5], dtype=np.uint32), ctx)
+        funcs.count_photons(np.int32(0), np.int32(n), np.uint32(event.SURFACE_ABSORB), counter, flags, block=(64, 1, 1), grid=(n // 64 + 1, 1))
+        assert int(counter.get()[0]) == 5 + np.count_nonzero(want.flags & event.SURFACE_ABSORB)
+        with pytest.raises(AttributeError):
+            funcs.no_such_kernel
+        with pytest.raises(KeyError):
+            get_cu_module('pdf.cu')
+        mesh = GPUFuncs(get_cu_module('mesh.h'))
+        o = cgpu.to_gpu(np.zeros(3 * 100, dtype=np.float32), ctx)
+        d = cgpu.to_gpu(np.tile([0.0, 0.0, 1.0], 100).astype(np.float32), ctx)
+        dist = GPUArray(100, np.float32, ctx).fill(np.float32(-1))
+        mesh.distance_to_mesh(np.int32(100), o, d, gg.gpudata, dist, block=(64, 1, 1), grid=(2, 1))
+        assert (dist.get() > 1000).all()
+    finally:
+        ctx.pop()
