@@ -129,6 +129,10 @@ SIGNATURES = {
     'chroma_daq_convert': (c_int32, [c_void_p, c_uint32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'chroma_generate_bomb': (c_int32, [c_void_p, POINTER(PhotonArrays), c_uint64, c_uint64, c_uint64,
                                        POINTER(c_float), c_float, c_float]),
+    'chroma_render': (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
+    'chroma_points_translate': (c_int32, [c_void_p, c_int32, c_void_p, POINTER(c_float)]),
+    'chroma_points_rotate': (c_int32, [c_void_p, c_int32, c_void_p, c_float, POINTER(c_float)]),
+    'chroma_points_rotate_around_point': (c_int32, [c_void_p, c_int32, c_void_p, c_float, POINTER(c_float), POINTER(c_float)]),
     'chroma_comm_unique_id': (c_int32, [c_void_p]),
     'chroma_comm_init': (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
     'chroma_comm_destroy': (c_int32, [c_void_p]),

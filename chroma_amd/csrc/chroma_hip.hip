@@ -2263,6 +2263,133 @@ k_distance_to_mesh(GeoView g, int nthreads, const float *origin, const float *di
     if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
 }
 
+// ---- render (chroma/cuda/render.cu:37-181) ---------------------------------------------------------------
+// One lane per ray: EVERY triangle along the ray (no nearest-hit pruning: intersect_node without a distance,
+// render.cu:107), the `alpha_depth` nearest kept as a list sorted by distance -- an equal distance goes in FRONT of
+// the ones already there (searchsorted/insert, sorting.h:64-98), so the order of discovery is part of the
+// result -- then composited front to back over the background colour.  The walk is therefore the reference's
+// own: its tree, its child order, its box arithmetic; the lists live in the caller's arrays (GPURays.dx /
+// .color / .dxlen), which is what lets a second render continue the first (keep_last_render).
+__device__ inline uint32_t render_searchsorted(uint32_t n, const float *arr, float x)       // sorting.h:64-87
+{
+    uint32_t jl = 0, ju = n;
+    const bool ascnd = arr[n - 1] >= arr[0];
+    while (ju - jl > 1) {
+        const uint32_t jm = (ju + jl) >> 1;
+        if ((x > arr[jm]) == ascnd) jl = jm; else ju = jm;
+    }
+    return ((x <= arr[0]) == ascnd) ? 0u : ju;
+}
+
+template <int LDS_N>
+__global__ __launch_bounds__(PROP_BLOCK) void
+k_render(GeoView g, const uint32_t *colors, int nthreads, const float *origin_in, const float *direction_in, uint32_t alpha_depth,
+         uint32_t *pixels, float *dx_all, uint32_t *dxlen, float4 *color_all, uint32_t bg_color, DeviceCounters *counters)
+{
+    __shared__ uint32_t s_lds[LDS_N * PROP_BLOCK];
+    const int id = blockIdx.x * PROP_BLOCK + threadIdx.x;
+    if (id >= nthreads) return;                    // (lanes are independent: no wave-wide votes below)
+    const v3 origin = load3(origin_in, id), direction = load3(direction_in, id);      // as given: NOT normalised (render.cu:57-58)
+    uint32_t n = dxlen[id];
+    const v3 noid = (-origin) / direction;
+    const v3 inv_dir = 1.0f / direction;
+    const v3 wo = mk3(g.world_origin[0], g.world_origin[1], g.world_origin[2]);
+    const float ws = g.world_scale;
+#define R_LO(nd) mk3(wo.x + (float)((nd).x & 0xFFFFu) * ws, wo.y + (float)((nd).y & 0xFFFFu) * ws, wo.z + (float)((nd).z & 0xFFFFu) * ws)
+#define R_HI(nd) mk3(wo.x + (float)((nd).x >> 16) * ws, wo.y + (float)((nd).y >> 16) * ws, wo.z + (float)((nd).z >> 16) * ws)
+    const uint4 root = g.nodes[0];
+    if (n < 1 && box_tmin(origin, noid, inv_dir, R_LO(root), R_HI(root), ws) < 0.0f) {
+        pixels[id] = bg_color;
+        return;
+    }
+    TravStack<LDS_N, PROP_BLOCK> stack;
+    stack.lds = s_lds + threadIdx.x;
+    int sp = 0;
+    bool overflow = false;
+    stack.put(sp++, root.w);
+    float *dx = dx_all + (size_t)id * alpha_depth;
+    float4 *color_a = color_all + (size_t)id * alpha_depth;
+    while (sp > 0 && !overflow) {
+        const uint32_t w = stack.get(--sp);
+        const uint32_t first = w & ~CHROMA_NCHILD_MASK, nchild = w >> CHROMA_CHILD_BITS;
+        for (uint32_t i = first; i < first + nchild; i++) {
+            const uint4 nd = g.nodes[i];
+            if (box_tmin(origin, noid, inv_dir, R_LO(nd), R_HI(nd), ws) < 0.0f) continue;
+            const uint32_t child = nd.w & ~CHROMA_NCHILD_MASK;
+            if ((nd.w >> CHROMA_CHILD_BITS) != 0) {
+                if (sp >= LDS_N + STACK_SCRATCH) { overflow = true; break; }      // cannot happen when the host check passed
+                stack.put(sp++, nd.w);
+                continue;
+            }
+            const float4 *t = g.tri + TRI_STRIDE * (size_t)child;                  // leaf: the triangle record (device order)
+            const float4 a = t[0], b = t[1], c = t[2];
+            const v3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(b.x, b.y, b.z), v2 = mk3(c.x, c.y, c.z);
+            float distance;
+            if (!intersect_triangle(origin, direction, v0, v1, v2, distance)) continue;
+            // get_color (render.cu:11-32)
+            const v3 normal = normalize(cross(v1 - v0, v2 - v1));
+            float cos_theta = dot(normal, -direction);
+            if (cos_theta < 0.0f) cos_theta = -cos_theta;
+            const uint32_t rgba = colors[__float_as_uint(b.w)];
+            const float4 color = make_float4((float)(0xffu & (rgba >> 16)) * cos_theta, (float)(0xffu & (rgba >> 8)) * cos_theta,
+                                             (float)(0xffu & rgba) * cos_theta, (float)(255u - (0xffu & (rgba >> 24))) / 255.0f);
+            if (n < 1) {
+                dx[0] = distance;
+                color_a[0] = color;
+            } else {
+                const uint32_t j = render_searchsorted(n, dx, distance);
+                if (j <= alpha_depth - 1u) {
+                    for (uint32_t k = alpha_depth - 1u; k > j; k--) { dx[k] = dx[k - 1]; color_a[k] = color_a[k - 1]; }     // sorting.h:89-98
+                    dx[j] = distance;
+                    color_a[j] = color;
+                }
+            }
+            if (n < alpha_depth) n++;
+        }
+    }
+#undef R_LO
+#undef R_HI
+    if (overflow) atomicAdd(&counters->stack_overflows, 1ull);
+    if (n < 1) {
+        pixels[id] = bg_color;
+        return;
+    }
+    dxlen[id] = n;
+    float scale = 1.0f, fr = 0.0f, fg = 0.0f, fb = 0.0f;
+    for (uint32_t i = 0; i < n; i++) {
+        const float4 ci = color_a[i];
+        const float alpha = ci.w;
+        fr += scale * ci.x * alpha;
+        fg += scale * ci.y * alpha;
+        fb += scale * ci.z * alpha;
+        scale *= (1.0f - alpha);
+    }
+    // (the reference divides by the double literal 255.0 here, render.cu:163)
+    const float alpha = (float)((double)(float)((bg_color & 0xFF000000u) >> 24) / 255.0);
+    fr += scale * (float)((bg_color & 0xFF0000u) >> 16) * alpha;
+    fg += scale * (float)((bg_color & 0xFF00u) >> 8) * alpha;
+    fb += scale * (float)(bg_color & 0xFFu) * alpha;
+    scale *= (1.0f - alpha);
+    const uint32_t av = (n < alpha_depth) ? cm_f2u32(cm_floorf(255.0f * (1.0f - scale))) : 255u;
+    const uint32_t red = cm_f2u32(cm_floorf(fr / (1.0f - scale)));
+    const uint32_t green = cm_f2u32(cm_floorf(fg / (1.0f - scale)));
+    const uint32_t blue = cm_f2u32(cm_floorf(fb / (1.0f - scale)));
+    pixels[id] = av << 24 | red << 16 | green << 8 | blue;
+}
+
+// chroma/cuda/transform.cu: translate / rotate / rotate_around_point of a point array
+__global__ void k_rays_transform(int n, float *a, int mode, float phi, float ax, float ay, float az, float px, float py, float pz)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    v3 p = load3(a, id);
+    const v3 axis = mk3(ax, ay, az), point = mk3(px, py, pz);
+    if (mode == 0) p = p + point;                                        // translate by `point`
+    else if (mode == 1) p = rotate(p, phi, axis);
+    else { p = p - point; p = rotate(p, phi, axis); p = p + point; }
+    store3(a, id, p);
+}
+
 // isotropic photon bomb (chroma/benchmark.py:77-83 with chroma/sample.py:16-30's formulas)
 __global__ void k_generate_bomb(PhotonView pv, uint64_t n, uint64_t seed, uint64_t id_base, float px, float py, float pz,
                                 float wl_lo, float wl_hi)
@@ -3569,6 +3696,39 @@ int chroma_daq_convert(chroma_ctx *ctx, uint32_t nchannels, float charge_unit, c
     HIP_TRY(hipGetLastError());
     return CHROMA_OK;
 }
+
+int chroma_render(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthreads, const float *d_origin, const float *d_direction,
+                  uint32_t alpha_depth, uint32_t *d_pixels, float *d_dx, uint32_t *d_dxlen, float *d_color, uint32_t bg_color)
+{
+    if (!ctx || !geom || !d_origin || !d_direction || !d_pixels || !d_dx || !d_dxlen || !d_color)
+        return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (alpha_depth < 1) return set_error(CHROMA_ERR_INVALID, "alpha_depth must be at least 1");
+    if (nthreads <= 0) return CHROMA_OK;
+    if (geom->stack_need > STACK_LDS + STACK_SCRATCH)
+        return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", geom->stack_need, STACK_LDS + STACK_SCRATCH);
+    hipLaunchKernelGGL((k_render<STACK_LDS>), dim3((unsigned)((nthreads + PROP_BLOCK - 1) / PROP_BLOCK)), dim3(PROP_BLOCK), 0, ctx->stream,
+                       geom->view, (const uint32_t *)geom->d_colors, (int)nthreads, d_origin, d_direction, alpha_depth, d_pixels, d_dx,
+                       d_dxlen, (float4 *)d_color, bg_color, ctx->d_counters);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
+static int rays_transform(chroma_ctx *ctx, int32_t n, float *d_a, int mode, float phi, const float axis[3], const float point[3])
+{
+    if (!ctx || !d_a) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (n <= 0) return CHROMA_OK;
+    const float zero[3] = {0.f, 0.f, 0.f};
+    if (!axis) axis = zero;
+    if (!point) point = zero;
+    hipLaunchKernelGGL(k_rays_transform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, d_a, mode, phi,
+                       axis[0], axis[1], axis[2], point[0], point[1], point[2]);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+int chroma_points_translate(chroma_ctx *ctx, int32_t n, float *d_a, const float v[3]) { return rays_transform(ctx, n, d_a, 0, 0.f, nullptr, v); }
+int chroma_points_rotate(chroma_ctx *ctx, int32_t n, float *d_a, float phi, const float axis[3]) { return rays_transform(ctx, n, d_a, 1, phi, axis, nullptr); }
+int chroma_points_rotate_around_point(chroma_ctx *ctx, int32_t n, float *d_a, float phi, const float axis[3], const float point[3])
+{ return rays_transform(ctx, n, d_a, 2, phi, axis, point); }
 
 int chroma_probe(chroma_ctx *ctx, int32_t fn, uint64_t n, const float *d_x, const float *d_tab_x, const float *d_tab_f,
                  uint32_t ntab, float start, float step, float *d_out)

@@ -7,3 +7,4 @@ from chroma_amd.gpu.detector import GPUDetector
 from chroma_amd.gpu.photon import GPUPhotons, GPUPhotonsSlice, generate_bomb
 from chroma_amd.gpu.daq import GPUDaq, GPUChannels
 from chroma_amd.gpu.funcs import get_cu_module, GPUFuncs
+from chroma_amd.gpu.render import GPURays

@@ -312,6 +312,17 @@ int chroma_generate_bomb(chroma_ctx *ctx, const chroma_photon_arrays *photons, u
                          uint64_t seed, uint64_t id_base, const float pos[3],
                          float wavelength_lo, float wavelength_hi);
 
+/* `render` (chroma/cuda/render.cu:37-181): every triangle along each ray, the `alpha_depth` nearest kept as
+ * a per-ray list sorted by distance (d_dx [n][alpha_depth], d_color [n][alpha_depth][4], d_dxlen [n]: in and
+ * out, so that a second call continues the first -- GPURays.render(keep_last_render=True)), composited
+ * front to back over bg_color into d_pixels [n] (0xAARRGGBB).  Directions are used as given (not normalised). */
+int chroma_render(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthreads, const float *d_origin, const float *d_direction,
+                  uint32_t alpha_depth, uint32_t *d_pixels, float *d_dx, uint32_t *d_dxlen, float *d_color, uint32_t bg_color);
+/* `translate`, `rotate`, `rotate_around_point` (chroma/cuda/transform.cu:9-53) on a float3 array */
+int chroma_points_translate(chroma_ctx *ctx, int32_t n, float *d_a, const float v[3]);
+int chroma_points_rotate(chroma_ctx *ctx, int32_t n, float *d_a, float phi, const float axis[3]);
+int chroma_points_rotate_around_point(chroma_ctx *ctx, int32_t n, float *d_a, float phi, const float axis[3], const float point[3]);
+
 /* ---- the hit reduction across the GPUs of a node ------------------------------
  * The reference has no multi-GPU mode.  Here one process drives one GPU, photons are sharded by
  * global id, the geometry is replicated, and the ONE exchange per batch is the per-channel arrays:

@@ -60,9 +60,18 @@ CM_FN int cm_f2i(float x)
     return (int)x;
 }
 
+/* float -> unsigned the same way (cvt.rzi.u32.f32 / v_cvt_u32_f32): NaN and negatives -> 0, saturating */
+CM_FN uint32_t cm_f2u32(float x)
+{
+    if (cm_isnan(x) || x <= 0.0f) return 0u;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+
 CM_FN float cm_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 CM_FN float cm_sqrtf(float x) { return __builtin_sqrtf(x); }
 CM_FN float cm_roundf(float x) { return __builtin_roundf(x); }   /* half away from zero, exact */
+CM_FN float cm_floorf(float x) { return __builtin_floorf(x); }
 
 /* ---- logf ------------------------------------------------------------- */
 CM_FN float cm_logf(float x)

@@ -209,6 +209,30 @@ def math_fn(fn, x, y=None, variant='contract'):
     return out
 
 
+def render(packed, origins, directions, alpha_depth=10, bg_color=0, state=None, variant='contract'):
+    """render.cu on host arrays.  ``state`` = (dx, dxlen, color) of a previous call (keep_last_render), else fresh.
+    Returns (pixels uint32, (dx [n][alpha_depth], dxlen [n], color [n][alpha_depth][4]))."""
+    lib = load(variant)
+    lib.oracle_render.restype = c_int32
+    lib.oracle_render.argtypes = [POINTER(_abi.GeometryDesc), c_uint64, c_void_p, c_void_p, c_uint32, c_uint32, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]
+    o = np.ascontiguousarray(origins, dtype=np.float32)
+    d = np.ascontiguousarray(directions, dtype=np.float32)
+    n = len(o)
+    if state is None:
+        dx = np.zeros((n, alpha_depth), dtype=np.float32)
+        dxlen = np.zeros(n, dtype=np.uint32)
+        color = np.zeros((n, alpha_depth, 4), dtype=np.float32)
+    else:
+        dx, dxlen, color = [np.array(a, copy=True) for a in state]
+    pixels = np.zeros(n, dtype=np.uint32)
+    rc = lib.oracle_render(ctypes.byref(packed.desc), n, o.ctypes.data, d.ctypes.data, int(alpha_depth), int(bg_color) & 0xFFFFFFFF,
+                           pixels.ctypes.data, dx.ctypes.data, dxlen.ctypes.data, color.ctypes.data)
+    if rc != 0:
+        raise RuntimeError('oracle_render failed (%d)' % rc)
+    return pixels, (dx, dxlen, color)
+
+
 PROBES = {'interp_property': 0, 'interp_idx': 1, 'interp': 2, 'rotate': 3}
 
 

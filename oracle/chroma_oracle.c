@@ -1055,6 +1055,108 @@ int oracle_distance_to_mesh(const chroma_geometry_desc *g, uint64_t n, const flo
     return oracle_intersect_mesh(g, n, origin, direction, NULL, distance, triangle, stats);
 }
 
+/* ---- render (chroma/cuda/render.cu) ------------------------------------------------------------------ */
+/* sorting.h:64-87 */
+static uint32_t render_searchsorted(uint32_t n, const float *arr, float x)
+{
+    uint32_t jl = 0, ju = n;
+    int ascnd = (arr[n - 1] >= arr[0]);
+    while (ju - jl > 1) {
+        uint32_t jm = (ju + jl) >> 1;
+        if ((x > arr[jm]) == ascnd) jl = jm; else ju = jm;
+    }
+    if ((x <= arr[0]) == ascnd) return 0;
+    return ju;
+}
+
+/* intersect_node without a distance (mesh.h:16-34, min_distance = -1) */
+static int box_hit(f3 noid, f3 inv_dir, const Node *node)
+{
+    float t;
+    return intersect_box(noid, inv_dir, node->lower, node->upper, &t);
+}
+
+/* render.cu:37-181 for host arrays: dx [n][alpha_depth], dxlen [n], color [n][alpha_depth][4] in and out */
+int oracle_render(const chroma_geometry_desc *g, uint64_t n, const float *origins, const float *directions, uint32_t alpha_depth,
+                  uint32_t bg_color, uint32_t *pixels, float *dx_all, uint32_t *dxlen, float *color_all)
+{
+    if (!g->colors || alpha_depth < 1) return -1;
+    for (uint64_t id = 0; id < n; id++) {
+        f3 origin = mk3(origins[3 * id], origins[3 * id + 1], origins[3 * id + 2]);
+        f3 direction = mk3(directions[3 * id], directions[3 * id + 1], directions[3 * id + 2]);
+        uint32_t cnt = dxlen[id];
+        Node root = get_node(g, 0);
+        f3 noid = div33(neg3(origin), direction);
+        f3 inv_dir = sdiv3(1.0f, direction);
+        if (cnt < 1 && !box_hit(noid, inv_dir, &root)) { pixels[id] = bg_color; continue; }
+        uint32_t child_ptr_stack[STACK_SIZE], nchild_ptr_stack[STACK_SIZE];
+        child_ptr_stack[0] = root.child;
+        nchild_ptr_stack[0] = root.nchild;
+        int curr = 0;
+        float *dx = dx_all + id * alpha_depth;
+        float *color_a = color_all + 4 * id * alpha_depth;
+        while (curr >= 0) {
+            uint32_t first_child = child_ptr_stack[curr], nchild = nchild_ptr_stack[curr];
+            curr--;
+            for (uint32_t i = first_child; i < first_child + nchild; i++) {
+                Node node = get_node(g, i);
+                if (!box_hit(noid, inv_dir, &node)) continue;
+                if (node.nchild != 0) {
+                    if (curr + 1 >= STACK_SIZE) return -2;
+                    curr++;
+                    child_ptr_stack[curr] = node.child;
+                    nchild_ptr_stack[curr] = node.nchild;
+                    continue;
+                }
+                f3 v0, v1, v2;
+                float distance;
+                get_triangle(g, node.child, &v0, &v1, &v2);
+                if (!intersect_triangle(origin, direction, v0, v1, v2, &distance)) continue;
+                /* get_color (render.cu:11-32) */
+                f3 normal = normalize3(cross3(sub3(v1, v0), sub3(v2, v1)));
+                float cos_theta = dot3(normal, neg3(direction));
+                if (cos_theta < 0.0f) cos_theta = -cos_theta;
+                uint32_t rgba = g->colors[node.child];
+                float col[4] = {(float)(0xffu & (rgba >> 16)) * cos_theta, (float)(0xffu & (rgba >> 8)) * cos_theta,
+                                (float)(0xffu & rgba) * cos_theta, (float)(255u - (0xffu & (rgba >> 24))) / 255.0f};
+                if (cnt < 1) {
+                    dx[0] = distance;
+                    memcpy(color_a, col, sizeof col);
+                } else {
+                    uint32_t j = render_searchsorted(cnt, dx, distance);
+                    if (j <= alpha_depth - 1u) {
+                        for (uint32_t k = alpha_depth - 1u; k > j; k--) { dx[k] = dx[k - 1]; memcpy(color_a + 4 * k, color_a + 4 * (k - 1), 16); }
+                        dx[j] = distance;
+                        memcpy(color_a + 4 * j, col, sizeof col);
+                    }
+                }
+                if (cnt < alpha_depth) cnt++;
+            }
+        }
+        if (cnt < 1) { pixels[id] = bg_color; continue; }
+        dxlen[id] = cnt;
+        float scale = 1.0f, fr = 0.0f, fg = 0.0f, fb = 0.0f;
+        for (uint32_t i = 0; i < cnt; i++) {
+            float alpha = color_a[4 * i + 3];
+            fr += scale * color_a[4 * i] * alpha;
+            fg += scale * color_a[4 * i + 1] * alpha;
+            fb += scale * color_a[4 * i + 2] * alpha;
+            scale *= (1.0f - alpha);
+        }
+        float alpha = (float)((double)(float)((bg_color & 0xFF000000u) >> 24) / 255.0);
+        fr += scale * (float)((bg_color & 0xFF0000u) >> 16) * alpha;
+        fg += scale * (float)((bg_color & 0xFF00u) >> 8) * alpha;
+        fb += scale * (float)(bg_color & 0xFFu) * alpha;
+        scale *= (1.0f - alpha);
+        uint32_t av = (cnt < alpha_depth) ? cm_f2u32(cm_floorf(255.0f * (1.0f - scale))) : 255u;
+        uint32_t red = cm_f2u32(cm_floorf(fr / (1.0f - scale)));
+        uint32_t green = cm_f2u32(cm_floorf(fg / (1.0f - scale)));
+        uint32_t blue = cm_f2u32(cm_floorf(fb / (1.0f - scale)));
+        pixels[id] = av << 24 | red << 16 | green << 8 | blue;
+    }
+    return 0;
+}
+
 /* Test order of the reference walk: the loop of intersect_mesh (mesh.h:58-110) with EVERY box test
  * succeeding and no triangle hit (so nothing is pruned).  order_out[k] = k-th triangle tested;
  * returns the number of tests, or -1 when the explicit stack (mesh.h: 1000 entries) would overflow.

@@ -294,3 +294,36 @@ def test_sample_cdf_reproduces_a_binned_gaussian(oracle_mod):
     assert abs(draws.mean()) < 0.06 and abs(draws.std() - 1.0) < 0.05
     ks = scipy.stats.kstest(draws, lambda x: np.interp(x, edges, cdf))
     assert ks.pvalue > 0.01, ks
+
+
+def test_render_restatement_invariants(oracle_mod):
+    """oracle_render (chroma/cuda/render.cu:37-181) on two nested cubes: a ray through the middle crosses four faces;
+    the per-ray lists are sorted, capped at alpha_depth (the nearest ones survive), misses show the background, and a
+    second call with the first call's lists (keep_last_render) merges instead of starting over."""
+    from chroma_amd.geometry import Geometry, Solid, vacuum
+    from chroma_amd.make import box
+    from chroma_amd.loader import create_geometry_from_obj
+    from chroma_amd.gpu.geometry import pack_geometry
+    from chroma_amd.tools import from_film
+    g = Geometry(vacuum)
+    g.add_solid(Solid(box(100.0, 100.0, 100.0), vacuum, vacuum, color=0x80FF0000))
+    g.add_solid(Solid(box(40.0, 40.0, 40.0), vacuum, vacuum, color=0x4000FF00))
+    pk = pack_geometry(create_geometry_from_obj(g))
+    pos, d = from_film(position=(0.0, -400.0, 0.0), size=(64, 48), width=35.0, focal_length=50.0)
+    pix, (dx, n, col) = oracle_mod.render(pk, pos, d, alpha_depth=10, bg_color=0x00000000)
+    # rays through both cubes, away from shared triangle edges: four hits at four different distances
+    four = np.flatnonzero((n == 4) & (dx[:, 0] < dx[:, 1]) & (dx[:, 1] < dx[:, 2]) & (dx[:, 2] < dx[:, 3]))
+    assert len(four) > 50 and n.max() <= 8 and (n == 0).any()
+    assert (pix[n == 0] == 0).all() and (pix[n > 0] >> 24 > 0).all()
+    for k in range(1, 4):
+        assert (dx[four, k] >= dx[four, k - 1]).all()
+    k0 = four[0]
+    assert 349.0 < dx[k0, 0] < 360.0 and 379.0 < dx[k0, 1] < 392.0 and 449.0 < dx[k0, 3] < 465.0
+    assert (col[four, 0, 0] > 200).all() and (col[four, 1, 1] > 200).all() and (col[four, 2, 1] > 200).all() and (col[four, 3, 0] > 200).all()
+    # alpha_depth 2 keeps the two nearest
+    pix2, (dx2, n2, _) = oracle_mod.render(pk, pos, d, alpha_depth=2)
+    assert n2.max() == 2 and np.array_equal(dx2[four], dx[four][:, :2])
+    assert (pix2[n2 == 2] >> 24 == 255).all()                              # a full list is opaque (render.cu:169-172)
+    # keep_last_render: the same rays again -> every distance twice, still sorted
+    pix3, (dx3, n3, _) = oracle_mod.render(pk, pos, d, alpha_depth=10, state=(dx, n, col))
+    assert (n3[four] == 8).all() and np.array_equal(dx3[four][:, 0:8:2], dx[four][:, :4]) and np.array_equal(dx3[four][:, 1:8:2], dx[four][:, :4])
