@@ -124,3 +124,29 @@ def test_single_triangle_and_degenerate_inputs():
         assert len(bvh) == 1 and bvh.nodes['w'][0] == 0
     with pytest.raises(Exception):
         make_recursive_grid_bvh(Mesh(np.zeros((3, 3)), np.zeros((0, 3), dtype=int)), backend='native')
+
+
+@pytest.mark.parametrize('case', ['tiny', 'box100', 'cube1000', 'sphere100_16'])
+def test_bvh_golden_layers_and_node_hash(case):
+    """SURVEY.md 8(c) golden 4: the full list of layer sizes, the world frame and the SHA-256 of the packed node
+    array against the committed tests/golden/bvh_golden.json (tools/gen_bvh_golden.py), for BOTH builders."""
+    import hashlib
+    import json
+    import os
+    import sys
+    from conftest import GOLDEN, ROOT
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from gen_bvh_golden import CASES
+    from chroma_amd.geometry import Geometry, Solid, Mesh
+    from chroma_amd.loader import create_geometry_from_obj
+    want = json.load(open(os.path.join(GOLDEN, 'bvh_golden.json')))[case]
+    geo = create_geometry_from_obj(CASES[case]())
+    for backend in ('native', 'numpy'):
+        bvh = make_recursive_grid_bvh(geo.mesh, backend=backend)
+        nodes = np.ascontiguousarray(bvh.nodes).view(np.uint32).reshape(-1, 4)
+        lo = [int(x) for x in bvh.layer_offsets]
+        assert [b - a for a, b in zip(lo, lo[1:] + [len(nodes)])] == want['layer_sizes'], backend
+        assert len(geo.mesh.triangles) == want['ntriangles'] and len(nodes) == want['nnodes']
+        assert float(np.float32(bvh.world_coords.world_scale)) == want['world_scale']
+        assert [float(np.float32(x)) for x in bvh.world_coords.world_origin] == want['world_origin']
+        assert hashlib.sha256(nodes.tobytes()).hexdigest() == want['nodes_sha256'], backend
