@@ -22,7 +22,13 @@ if os.path.exists(path):
     out = json.load(open(path))
 f, nf = total(fetch_dir, 'FETCH_SIZE', kernel)
 w, nw = total(write_dir, 'WRITE_SIZE', kernel)
+import datetime, hashlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for name in ('chroma_amd/csrc/chroma_hip.hip', 'chroma_amd/csrc/propagate_device.h', 'chroma_amd/csrc/device_common.h', 'include/chroma_math.h'):
+    h.update(open(os.path.join(root, name), 'rb').read())
 out[key] = {'kernel': kernel, 'launches': nf, 'fetch_size_kb_sum': f, 'write_size_kb_sum': w,
+            'source_hash': h.hexdigest()[:12], 'date': datetime.date.today().isoformat(),
             'hbm_bytes_per_launch': (2.0 * f + w) * 1024.0 / max(nf, 1),
             'correction': 'FETCH_SIZE x2 (gfx950, calibrated with tools/calib_fetch.hip), WRITE_SIZE x1'}
 json.dump(out, open(path, 'w'), indent=1)

@@ -1,10 +1,12 @@
 #!/bin/bash
-# One GPU-box pass that refreshes the judged artefacts: GPU tests, the bench lines of every config and the
-# rocprofv3 kernel summary of the default bench command.  usage: tools/refresh_profiles.sh OUTDIR
+# One GPU-box pass that refreshes the judged artefacts: GPU tests, the bench lines of every config, the
+# rocprofv3 kernel summary of the default bench command and its HBM-traffic counters (FETCH_SIZE / WRITE_SIZE in
+# separate --pmc passes, no trace flags beside them).  usage: tools/refresh_profiles.sh OUTDIR
 set -u
 out=$1
 mkdir -p $out
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > $out/gpu_tests.log 2>&1 || { tail -20 $out/gpu_tests.log; exit 1; }
+export CHROMA_BENCH_GEOMETRY_CACHE=/dev/shm/chroma_geo_cache
+timeout -k 10 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $out/gpu_tests.log 2>&1 || { tail -20 $out/gpu_tests.log; exit 1; }
 tail -1 $out/gpu_tests.log
 python bench.py > $out/bench_c3_default.json 2> $out/bench_c3_default.log || exit 1
 for cfg in tiny lite c5 detector; do
@@ -13,4 +15,14 @@ done
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_c3 -- python3 bench.py --no-cpu-baseline > $out/rocprof_c3.json 2> $out/rocprof_c3.log || exit 1
 python tools/prof_summary.py $out/rocprof_c3 $out/rocprof_c3_default_summary.txt bench.py
+rm -rf $out/rocprof_c3
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 5 300 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $out/pmc_$c.stdout 2> $out/pmc_$c.stderr || exit 1
+done
+python tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE c3:100000000:100 > $out/pmc_traffic.txt
+python tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE c3:100000000:100:physics k_physics >> $out/pmc_traffic.txt
+cat $out/pmc_traffic.txt
+rm -rf $out/pmc_FETCH_SIZE/*/*agent_info.csv
+python bench.py --no-cpu-baseline > $out/bench_c3_with_traffic.json 2> $out/bench_c3_with_traffic.log
+rm -rf /dev/shm/chroma_geo_cache
 cat $out/bench_*.json
