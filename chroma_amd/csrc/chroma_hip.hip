@@ -1817,8 +1817,14 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
             if (!fixup && tri >= 0) {
                 // is the fast walk's winner one the reference is sure to find too?
                 const float4 *t = g.tri + TRI_STRIDE * (size_t)tri;
-                if (!record_hit_is_plainly_regular(g, t[0], t[1], t[2], p.position, p.direction, hit_dist)) {
-                    retry_list[atomicAdd(&st->retry, 1u)] = (uint32_t)slot;       // (k_raycast_retry asks the exact question)
+                // (the plain build leaves the exact question to k_raycast_retry: it is rare there -- hits within ulps of
+                //  a leaf box's upper face -- and its divisions cost registers; the all-models build asks it here, because
+                //  the geometries it serves (faces ON the world box: every hit "near a face") would send everything round)
+                const float4 ta = t[0], tb = t[1], tc = t[2];
+                const bool regular = FULL ? record_hit_is_regular(g, ta, tb, tc, p.position, p.direction, hit_dist)
+                                          : record_hit_is_plainly_regular(g, ta, tb, tc, p.position, p.direction, hit_dist);
+                if (!regular) {
+                    retry_list[atomicAdd(&st->retry, 1u)] = (uint32_t)slot;
                     tri = HIT_RETRY;
                 }
             }
@@ -2574,18 +2580,21 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
         hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                            ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
                            ctx->retry_list, 0, pc);
+    // (both passes stride over the list and leave at once when it is short -- the usual case -- but a plain geometry
+    //  with faces on the world box lists a good part of its hits for the exact check: grids for that)
+    const unsigned rblocks = (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK, 8 * 256);
     if (ctx->counting)
-        hipLaunchKernelGGL((k_raycast_retry<true>), dim3(256), block, 0, ctx->stream, geom->view, ctx->rays, st,
+        hipLaunchKernelGGL((k_raycast_retry<true>), dim3(rblocks), block, 0, ctx->stream, geom->view, ctx->rays, st,
                            ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
     else
-        hipLaunchKernelGGL((k_raycast_retry<false>), dim3(256), block, 0, ctx->stream, geom->view, ctx->rays, st,
+        hipLaunchKernelGGL((k_raycast_retry<false>), dim3(rblocks), block, 0, ctx->stream, geom->view, ctx->rays, st,
                            ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
     if (plain)
-        hipLaunchKernelGGL((k_physics<false>), dim3(std::min(pblocks, 64u)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
+        hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
                            work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
                            scatter_first, ctx->retry_list, 1, pc);
     else
-        hipLaunchKernelGGL((k_physics<true>), dim3(std::min(pblocks, 64u)), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
+        hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
                            work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
                            scatter_first, ctx->retry_list, 1, pc);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
