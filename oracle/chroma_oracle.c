@@ -13,15 +13,22 @@
  * (0,1] the way curand_uniform does (include/chroma_math.h); draws are taken in
  * exactly the order the reference takes them.
  *
- * PARITY PIN STATUS
- *   - ray cast (intersect_mesh / intersect_box / intersect_triangle / get_node):
- *     pinned against the reference's own chroma/cuda/mesh.h compiled for gfx950 by
- *     oracle/Makefile (oracle/_ref, runs on the GPU box: tests/test_gpu_ref_mesh.py).
- *   - physics (photon.h): the reference's device code needs curand_kernel.h and
- *     cuComplex.h, which this image lacks, so it is unbuildable here; the reference
- *     holds no golden vectors for it, only statistical tests (test/test_rayleigh.py,
- *     test/test_propagation.py), which tests/ restate.  Bit-level parity of the
- *     physics with the CUDA reference is therefore UNPINNED ("parity unpinned").
+ * PARITY PIN STATUS (the reference's own sources compiled for gfx950 by oracle/Makefile into oracle/_ref,
+ * from where they lie, nothing copied; the tests run on the GPU box)
+ *   - ray cast (intersect_mesh / intersect_box / intersect_triangle / get_node, with last_hit_triangle and
+ *     with rays through vertices and edges, where the reference's test order decides): PINNED on
+ *     chroma/cuda/mesh.h (tests/test_gpu_ref_mesh.py).
+ *   - interp_property, interp_idx, interp (the DAQ's CDF sampling), rotate: PINNED on chroma/cuda/geometry.h,
+ *     interpolate.h, rotate.h (tests/test_gpu_ref_headers.py; rotate: the algebra -- its cosine is the numeric
+ *     contract's, the reference calls the device library's).
+ *   - render: PINNED on chroma/cuda/render.cu (tests/test_gpu_render.py).
+ *   - host tables, meshes, spiral, flatten: PINNED on vectors made by importing the reference's NumPy modules
+ *     (tests/golden/ref_host_model.npz, tools/gen_golden.py).
+ *   - physics (photon.h, random.h, cx.h) and daq.cu: the reference's device code needs curand_kernel.h and
+ *     cuComplex.h, bvh.cu needs cuda.h; this image has none of them, so they are unbuildable here (no stand-in
+ *     headers were written); the reference holds no golden vectors for them, only statistical tests
+ *     (test/test_rayleigh.py, test/test_propagation.py, test/test_detector.py), which tests/ restate.  Bit-level
+ *     parity of the physics with the CUDA reference is therefore UNPINNED ("parity unpinned").
  */
 #include <stdint.h>
 #include <stdlib.h>
