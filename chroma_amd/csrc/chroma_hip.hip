@@ -918,6 +918,9 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #ifndef QUAD_UNIFORM_SPILL
 #define QUAD_UNIFORM_SPILL 1   // the spill paths of push and pop behind one wave-uniform test each
 #endif
+#ifndef QUAD_TIMING
+#define QUAD_TIMING 0        // diagnostic build: s_memtime stamps around the phases of a wave, printed by a few waves
+#endif
 #ifndef QUAD_SETPRIO
 #define QUAD_SETPRIO 1       // s_setprio around the node fetch (-0.6 %)
 #endif
@@ -1002,8 +1005,18 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     uint32_t phead = 0;                     // first postponed triangle in the ring
     uint32_t loc_next = 0, loc_end = 0;
     bool exhausted = false;
+#if QUAD_TIMING
+    // where a wave's cycles go (diagnostic build, tools/quad_timing.sh): s_memtime stamps around the phases
+    unsigned long long tq_refill = 0, tq_pop = 0, tq_wait = 0, tq_node = 0, tq_leaf = 0, tq_retire = 0, tq_a, tq_b;
+    unsigned tq_iters = 0, tq_rounds = 0, tq_outer = 0, tq_active = 0, tq_tests = 0;
+#define TQ_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+    const unsigned long long tq_start = __builtin_readcyclecounter();
+#endif
 
     for (;;) {
+#if QUAD_TIMING
+        TQ_STAMP(tq_a); tq_outer++;
+#endif
         // ---- refill idle quads
         unsigned long long idle_mask = __ballot(!has_ray && j == 0);
         int n_idle = __popcll(idle_mask);
@@ -1049,10 +1062,16 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
             continue;
         }
 
+#if QUAD_TIMING
+        TQ_STAMP(tq_b); tq_refill += tq_b - tq_a;
+#endif
         // ---- node phase: every active quad visits one node per iteration
         more = !exhausted || loc_next < loc_end;
         const int stop_at = more ? max(0, (int)__popcll(__ballot(active && j == 0)) - (int)QUAD_REFILL_MIN) : 0;
         do {
+#if QUAD_TIMING
+            TQ_STAMP(tq_a); tq_iters++; tq_active += (unsigned)__popcll(__ballot(active && j == 0));
+#endif
 #if QUAD_SETPRIO
             __builtin_amdgcn_s_setprio(3);       // a wave about to fetch its next node goes before waves that compute
 #endif
@@ -1079,9 +1098,16 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 }
                 if (cur == WIDE_NONE) active = false;
             }
+#if QUAD_TIMING
+            TQ_STAMP(tq_b); tq_pop += tq_b - tq_a;
+#endif
             if (active) {
                 const uint4 *np = g.wnodes + 8 * (size_t)cur + 2 * j;       // this lane's two entries: 32 bytes
                 const uint4 ea = np[0], eb = np[1];
+#if QUAD_TIMING
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                TQ_STAMP(tq_a); tq_wait += tq_a - tq_b;
+#endif
 #if QUAD_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1143,11 +1169,20 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     }
                 }
             }
+#if QUAD_TIMING
+            TQ_STAMP(tq_b); tq_node += tq_b - tq_a;       // (a_ = after the wait when the wave fetched, else the pop stamp)
+#endif
         } while (!__any(npend >= QUAD_FLUSH) && __popcll(__ballot(active && j == 0)) > stop_at);
         __builtin_amdgcn_wave_barrier();      // (scheduling fence: the lanes of a quad exchange data through LDS)
+#if QUAD_TIMING
+        TQ_STAMP(tq_a);
+#endif
 
         // ---- leaf phase: up to 4 postponed triangles of a ray at once, one per lane
         while (__any(npend > 0)) {
+#if QUAD_TIMING
+            tq_rounds++; tq_tests += (unsigned)__popcll(__ballot(npend > 0 && (int)j < min(npend, 4)));
+#endif
             if (npend > 0) {
                 const int take = min(npend, 4);
                 bool hit = false;
@@ -1182,6 +1217,9 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
         }
 
 
+#if QUAD_TIMING
+        TQ_STAMP(tq_b); tq_leaf += tq_b - tq_a;
+#endif
         // ---- retire finished rays
         if (has_ray && !active) {
             if (j == 0) {
@@ -1193,6 +1231,13 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
         }
     }
 
+#if QUAD_TIMING
+    if (lane == 0 && (blockIdx.x & 1023u) == 0u && nthreads > 1000000) {
+        const unsigned long long total = __builtin_readcyclecounter() - tq_start;
+        printf("QT rays %d wave %u total %llu refill %llu pop %llu wait %llu node %llu leaf %llu outer %u iters %u active %u rounds %u tests %u\n",
+               nthreads, blockIdx.x, total, tq_refill, tq_pop, tq_wait, tq_node, tq_leaf, tq_outer, tq_iters, tq_active, tq_rounds, tq_tests);
+    }
+#endif
     if (COUNT) {
         unsigned long long nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris);
         if (lane == 0) {
