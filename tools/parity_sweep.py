@@ -1,5 +1,5 @@
 """Large-sample parity sweep on the GPU box: engine vs oracle, bit for bit, on random bombs and on rays
-aimed at mesh vertices/edges from several origins.  usage: parity_sweep.py [config] [photons per batch] [batches]"""
+aimed at mesh vertices/edges from several origins.  usage: parity_sweep.py [tiny|lite|detector|c3|c5] [photons per batch] [batches]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,10 +13,12 @@ from chroma_amd.gpu.geometry import pack_geometry
 config = sys.argv[1] if len(sys.argv) > 1 else 'tiny'
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 5_000_000
 batches = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-geo = create_geometry_from_obj({'tiny': demo.tiny, 'lite': demo.detector_lite}[config]())
+geo = create_geometry_from_obj({'tiny': demo.tiny, 'lite': demo.detector_lite, 'detector': demo.detector, 'c3': demo.detector29k,
+                                'c5': demo.scintillator_stress}[config]())
 pk = pack_geometry(geo)
 gpu.create_cuda_context(0)
-gg = gpu.GPUDetector(geo)
+gg = gpu.GPUDetector(geo, packed=pk)
+wl0 = 350.0 if config == 'c5' else 400.0
 FIELDS = ('flags', 'last_hit_triangles', 'pos', 'dir', 'pol', 't', 'wavelengths')
 
 
@@ -24,7 +26,7 @@ def compare(ph, seed, what):
     rs = gpu.get_rng_states(64, seed=seed)
     gp = gpu.GPUPhotons(ph)
     t0 = time.time(); gp.propagate(gg, rs, max_steps=100); got = gp.get(); t1 = time.time()
-    want, _, _ = oracle.propagate(pk, ph, seed=seed, max_steps=100, nthreads=os.cpu_count())
+    want, _, _ = oracle.propagate(pk, ph, seed=seed, max_steps=100, nthreads=min(64, len(os.sched_getaffinity(0))))
     t2 = time.time()
     bad = np.zeros(len(ph), dtype=bool)
     for f in FIELDS:
@@ -37,7 +39,7 @@ def compare(ph, seed, what):
 
 total = 0
 for b in range(batches):
-    ph = oracle.generate_bomb(n, seed=1000 + b, wavelength_lo=400.0, wavelength_hi=700.0 if b % 2 else 0.0)
+    ph = oracle.generate_bomb(n, seed=1000 + b, wavelength_lo=wl0, wavelength_hi=700.0 if b % 2 else 0.0)
     total += compare(ph, 500 + b, 'bomb seed %d' % (1000 + b))
 # aimed rays from a few origins
 m = geo.mesh
@@ -51,6 +53,6 @@ for origin in ([0, 0, 0], [300.0, -200.0, 150.0], [0.0, 0.0, 1200.0]):
     d = d[np.linalg.norm(d, axis=1) > 1e-9]
     d /= np.linalg.norm(d, axis=1)[:, None]
     pol = np.cross(d, np.roll(d, 1, axis=1) + 1e-3); pol /= np.linalg.norm(pol, axis=1)[:, None]
-    ph = Photons(np.tile(np.asarray(origin, dtype=float), (len(d), 1)), d, pol, np.full(len(d), 400.0))
+    ph = Photons(np.tile(np.asarray(origin, dtype=float), (len(d), 1)), d, pol, np.full(len(d), wl0))
     total += compare(ph, 77, 'aimed from %s' % (origin,))
 print('TOTAL differing photons:', total)
