@@ -205,3 +205,45 @@ def test_c5_full_batch_matches_the_oracle(gpu, oracle_mod, c5):
 def test_c5_full_batch_properties(gpu, c5):
     batch_properties(gpu, c5, 10_000_000, id_base=1 << 34, wavelength=350.0, max_nan_fraction=1e-4)
     walks_agree(gpu, c5, 2_000_000, id_base=1 << 34, wavelength=350.0, walks=('pair', 'coop', 'reference'))
+
+
+def test_c2_the_known_erratic_moller_trumbore_ray(gpu, oracle_mod, c2):
+    """The one known class in which the nearest-first walks and the reference's own walk differ:
+    a ray that runs almost inside a triangle's plane gets a numerically erratic Moeller-Trumbore "hit" 500 mm in FRONT
+    of that triangle's leaf box.  The reference's depth-first order tests the triangle before it knows a nearer hit
+    and keeps the bogus distance; oracle, compiled reference and the engine's literal walk agree on it.  The fast
+    walks find the true nearest hit first and prune the box unseen.  Found by tools/parity_sweep.py detector
+    (1 of 1.08e6 aimed rays; 0 of 1e7 random photons); pinned here so that the diagnosis stays true."""
+    import ctypes
+    import os
+    from chroma_amd import _lib
+    from chroma_amd.gpu.tools import to_gpu, GPUArray
+    from conftest import ROOT
+    o = np.array([[300.0, -200.0, 150.0]], dtype=np.float32)
+    d = np.array([[0.3109407126903534, 0.7269728183746338, 0.612230658531189]], dtype=np.float32)
+    odist, otri, _ = oracle_mod.distance_to_mesh(c2.packed, o, d)
+    assert otri[0] == 11290059 and abs(float(odist[0]) - 13591.27) < 0.01
+    # the bogus distance lies in front of the triangle it is attributed to (nearest vertex: 14 100 mm away)
+    verts = c2.geometry.mesh.vertices[c2.geometry.mesh.triangles[11290059]]
+    assert np.linalg.norm(verts - o[0], axis=1).min() > 14090.0
+    ctx = gpu.get_context()
+
+    def cast(walk):
+        ctx.set_walk(walk)
+        try:
+            dist = GPUArray(1, np.float32, ctx).fill(np.float32(np.nan))
+            tri = GPUArray(1, np.int32, ctx)
+            d_o, d_d = to_gpu(o.reshape(-1), ctx), to_gpu(d.reshape(-1), ctx)
+            _lib.check(ctx._lib.chroma_distance_to_mesh(ctx.handle, c2.gg.handle, 1, d_o.ptr, d_d.ptr, dist.ptr, tri.ptr))
+            return int(tri.get()[0]), float(dist.get()[0])
+        finally:
+            ctx.set_walk('quad')
+    lit = cast('reference')
+    assert lit[0] == 11290059 and np.float32(lit[1]).view(np.uint32) == odist.view(np.uint32)[0]       # the literal walk: the reference's answer
+    fast = cast('quad')
+    assert fast[0] == 11287755 and abs(fast[1] - 13886.08) < 0.01                                      # nearest-first: the true nearest hit
+    ref_lib = os.path.join(ROOT, 'oracle', '_ref', 'libchroma_ref_mesh.so')
+    if os.path.exists(ref_lib):
+        from test_gpu_ref_mesh import _ref_cast
+        rdist, rtri = _ref_cast(ctypes.CDLL(ref_lib), c2.geometry, o, d)
+        assert rtri[0] == otri[0] and rdist.view(np.uint32)[0] == odist.view(np.uint32)[0]
