@@ -1817,6 +1817,10 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
 #ifndef PHYS_WAVES_PER_EU
 #define PHYS_WAVES_PER_EU 4
 #endif
+#ifndef PHYS_SORT
+#define PHYS_SORT 1          // deal the slots of a block to its threads by the kind of surface hit
+#endif
+#define PHYS_CLASSES 8
 #ifndef PHYS_PLAIN_WAVES_PER_EU
 #define PHYS_PLAIN_WAVES_PER_EU 4
 #endif
@@ -1833,6 +1837,14 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
     // taken as they are.  A photon that survives the step is appended to the next working set; one that
     // ends here is written to the caller's arrays (the only time they are touched).
     __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
+#if PHYS_SORT
+    // The 512 slots of a round are dealt to the threads BY THE SURFACE THEY HIT (the material code of the winning
+    // triangle's record): what a photon does at a black wall, at PMT glass, at the photocathode or at a mirror are
+    // different, long branches (Fresnel alone is a third of the kernel), and a wave that holds all kinds executes
+    // them all.  Sorted, most waves hold one kind and skip the rest.  Only slot numbers move (through LDS).
+    __shared__ uint32_t s_class_count[PHYS_BLOCK / WAVE][PHYS_CLASSES];
+    __shared__ int32_t s_perm[PHYS_BLOCK];
+#endif
     const int nthreads = fixup ? (int)st->retry : (int)st->n, renorm = (int)st->renorm;
     unsigned long long nsteps = 0;
     // the grid is sized for an upper bound of the photon count: blocks stride over the slots
@@ -1843,8 +1855,49 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
     Photon p;
     uint32_t counter = 0;
     int last_hit_record = -1;
+#if PHYS_SORT
+    int sorted_slot = (id < nthreads) ? id : -1;
+    if (!fixup) {
+        // class of this thread's own slot: 0 = nothing to do here (no slot, miss, NaN, retry), else 1 + surface kind
+        uint32_t cls = 0;
+        if (id < nthreads) {
+            const int tri0 = hit_triangle[id];
+            if (tri0 >= 0) {
+                const uint32_t code = __float_as_uint(g.tri[TRI_STRIDE * (size_t)tri0].w);
+                const int surface = convert(0xFF & (code >> 8));                       // -1: no surface (a material boundary)
+                cls = 1u + (uint32_t)min(surface + 1, PHYS_CLASSES - 2);
+            }
+        }
+        const unsigned lane = lane_id(), wave = threadIdx.x / WAVE;
+        uint32_t my_rank = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < PHYS_CLASSES; c++) {
+            const unsigned long long m = __ballot(cls == c);
+            if (cls == c) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_class_count[wave][c] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        // start of (class, wave) in the sorted order -- classes in order, waves within a class: one wave scans the 64 counts
+        static_assert(PHYS_CLASSES * (PHYS_BLOCK / WAVE) == WAVE, "one lane per (class, wave) pair");
+        if (wave == 0) {
+            const uint32_t c = lane / (PHYS_BLOCK / WAVE), w = lane % (PHYS_BLOCK / WAVE);
+            const uint32_t k = s_class_count[w][c];
+            uint32_t incl = k;
+            for (int off = 1; off < WAVE; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
+            s_class_count[w][c] = incl - k;
+        }
+        __syncthreads();
+        s_perm[s_class_count[wave][cls] + my_rank] = (id < nthreads) ? id : -1;
+        __syncthreads();
+        sorted_slot = s_perm[threadIdx.x];
+        __syncthreads();               // (the tables are rewritten by the next round)
+    }
+    if (sorted_slot >= 0) {
+        const int slot = fixup ? (int)retry_list[sorted_slot] : sorted_slot;
+#else
     if (id < nthreads) {
         const int slot = fixup ? (int)retry_list[id] : id;
+#endif
         int tri = hit_triangle[slot];
         const float hit_dist = hit_distance[slot];
         float4 w0, w1, w2, w3;
