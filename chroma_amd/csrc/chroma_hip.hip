@@ -927,6 +927,18 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #ifndef QUAD_FLUSH
 #define QUAD_FLUSH 8         // run the triangle tests once a ray has this many postponed (a visit adds up to 8)
 #endif
+#ifndef QUAD_TRIGGER_LANES
+#define QUAD_TRIGGER_LANES 0 // (experiment) also run a round once this many lanes of the wave would have a triangle to test; 0 = off
+#endif
+#ifndef QUAD_POP_SELECT
+#define QUAD_POP_SELECT 1
+#endif
+#ifndef QUAD_LEAF_SELECT
+#define QUAD_LEAF_SELECT 1
+#endif
+#ifndef QUAD_KEEP
+#define QUAD_KEEP 7          // a triangle phase runs rounds until no ray with node work left holds more than this many (7: one round unless a ray holds 12+; -5 % against 0)
+#endif
 
 __device__ inline uint32_t quad_min_u32(uint32_t v)
 {
@@ -975,7 +987,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
     const int chunk = ((long long)nthreads > 4ll * big_chunk * (long long)gridDim.x) ? big_chunk : 16;
     static_assert(PROP_BLOCK == WAVE, "one wave per workgroup");
-    static_assert((QUAD_PENDING & (QUAD_PENDING - 1)) == 0 && QUAD_FLUSH - 1 + 8 <= QUAD_PENDING, "ring of postponed triangles");
+    static_assert((QUAD_PENDING & (QUAD_PENDING - 1)) == 0 && QUAD_FLUSH - 1 + 8 <= QUAD_PENDING && QUAD_KEEP < QUAD_FLUSH, "ring of postponed triangles");
     __shared__ uint32_t s_lds[16 * QUAD_STRIDE];
     const unsigned lane = lane_id();
     const unsigned j = lane & 3u, gshift = lane & ~3u, grp = lane >> 2;
@@ -1077,6 +1089,16 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #endif
 #if QUAD_UNIFORM_SPILL
             if (!__any(sp > QUAD_STACK)) {
+#if QUAD_POP_SELECT
+                // (node, distance) read together, the entry kept or dropped by a select: no branch inside the loop
+                while (active && cur == WIDE_NONE) {
+                    if (sp == 0) { active = false; break; }
+                    sp--;
+                    const uint32_t n = stack_n[sp];
+                    const float t = stack_t[sp];
+                    cur = (t > prune_t) ? WIDE_NONE : n;
+                }
+#else
                 if (active && cur == WIDE_NONE) {
                     while (sp > 0) {
                         sp--;
@@ -1086,6 +1108,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     }
                     if (cur == WIDE_NONE) active = false;
                 }
+#endif
             } else
 #endif
             if (active && cur == WIDE_NONE) {
@@ -1172,17 +1195,51 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #if QUAD_TIMING
             TQ_STAMP(tq_b); tq_node += tq_b - tq_a;       // (a_ = after the wait when the wave fetched, else the pop stamp)
 #endif
-        } while (!__any(npend >= QUAD_FLUSH) && __popcll(__ballot(active && j == 0)) > stop_at);
+        } while (!__any(npend >= QUAD_FLUSH) && __popcll(__ballot(active && j == 0)) > stop_at &&
+                 !(QUAD_TRIGGER_LANES && (int)__popcll(__ballot((int)j < npend)) >= QUAD_TRIGGER_LANES));
         __builtin_amdgcn_wave_barrier();      // (scheduling fence: the lanes of a quad exchange data through LDS)
 #if QUAD_TIMING
         TQ_STAMP(tq_a);
 #endif
 
         // ---- leaf phase: up to 4 postponed triangles of a ray at once, one per lane
-        while (__any(npend > 0)) {
+        while (__any(npend > (active ? QUAD_KEEP : 0))) {
 #if QUAD_TIMING
             tq_rounds++; tq_tests += (unsigned)__popcll(__ballot(npend > 0 && (int)j < min(npend, 4)));
 #endif
+#if QUAD_LEAF_SELECT
+            {
+                // every lane runs the round; a ray without postponed triangles takes none and keeps its state
+                // through selects (the reductions are a few DPP operations: cheaper than the copies that
+                // branches around them cost)
+                const int take = min(npend, 4);
+                bool hit = false;
+                float distance = 0.0f;
+                uint32_t tri = 0, rank = 0xFFFFFFFFu;
+                if ((int)j < take) {
+                    tri = pending[(phead + j) & (QUAD_PENDING - 1u)];
+                    if (COUNT) cnt.tris++;
+                    const float4 *tp = g.tri + TRI_STRIDE * (size_t)tri;
+                    float4 a = tp[0], b = tp[1], c = tp[2];
+                    hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
+                    rank = __float_as_uint(c.w);
+                }
+                const uint32_t dkey = hit ? __float_as_uint(distance) : 0x7F800000u;
+                const uint32_t dmin = quad_min_u32(dkey);
+                const float dm = __uint_as_float(dmin);
+                const bool cand = hit && dkey == dmin;
+                const uint32_t rm = quad_min_u32(cand ? rank : 0xFFFFFFFFu);
+                const uint32_t wtri = quad_max_u32((cand && rank == rm) ? tri + 1u : 0u) - 1u;
+                const bool better = dmin != 0x7F800000u &&
+                                    (triangle_index == -1 || dm < min_distance || (dm == min_distance && rm < best_rank));
+                triangle_index = better ? (int)wtri : triangle_index;
+                min_distance = better ? dm : min_distance;
+                prune_t = better ? dm : prune_t;
+                best_rank = better ? rm : best_rank;
+                phead = (phead + (uint32_t)take) & (QUAD_PENDING - 1u);
+                npend -= take;
+            }
+#else
             if (npend > 0) {
                 const int take = min(npend, 4);
                 bool hit = false;
@@ -1214,6 +1271,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 phead = (phead + (uint32_t)take) & (QUAD_PENDING - 1u);
                 npend -= take;
             }
+#endif
         }
 
 

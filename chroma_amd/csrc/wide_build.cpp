@@ -290,7 +290,127 @@ static uint32_t build_subtree(Prim *prims, size_t first, size_t count, std::vect
     return me;
 }
 
-static int sah_topology(const uint32_t *ref, uint32_t ntriangles, const std::vector<uint32_t> &leaf_node, WideTree &out, std::string &err)
+// ---- the same sets as a BINARY tree first, then collapsed to eight-wide nodes at the least total area ----
+// The greedy rule above ("split the largest part until there are eight") fills a node with whatever sizes
+// the binary SAH splits happen to give: near the bottom of the tree it leaves many wide nodes with two or
+// three triangles (C3: 71 % of all entries used), and every such node is a visit -- one dependent fetch
+// and a pass of the walk's bookkeeping -- that tests few boxes.  Here a task's triangles are first split
+// all the way down to single triangles (the same binned / swept SAH splits), and the binary tree is then
+// cut into wide nodes by the dynamic programme of Ylitie, Karras & Laine ("Efficient incoherent ray
+// traversal on GPUs through compressed wide BVHs", HPG 2017, section 4.1, with one triangle per leaf
+// entry): D(n, k) = least sum of wide-node areas below binary node n when n may use k entries of its
+// parent -- as ONE entry it becomes a wide node of its own, area(n) + best distribution of eight entries
+// over its two children; with k >= 2 entries it may instead dissolve into the parent, its children sharing
+// the k entries.  The sum of the areas is the SAH estimate of the number of node visits per ray.
+struct BinNode { uint16_t lo[3], hi[3]; uint32_t left, right; };     // leaf: left = 0xFFFFFFFF, right = prim position
+static const uint32_t BIN_LEAF = 0xFFFFFFFFu;
+
+static inline double bin_area(const BinNode &b)
+{
+    double dx = (double)(b.hi[0] - b.lo[0]), dy = (double)(b.hi[1] - b.lo[1]), dz = (double)(b.hi[2] - b.lo[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+struct DpScratch {
+    std::vector<BinNode> bin;
+    std::vector<float> cost;          // [node][8]: D(n, k), k = 1..8
+    std::vector<uint8_t> left_share;  // [node][8]: entries given to the left child when n's children share k entries (k >= 2; [..][0] for its own eight)
+    std::vector<uint8_t> own_node;    // [node][8]: D(n, k) is reached by n being a wide node of its own
+};
+
+static void emit_entries(const DpScratch &d, uint32_t n, int k, uint32_t *items, int &nitems)
+{
+    const BinNode &b = d.bin[n];
+    if (b.left == BIN_LEAF || k == 1 || d.own_node[(size_t)n * 8 + (k - 1)]) { items[nitems++] = n; return; }
+    const int j = d.left_share[(size_t)n * 8 + (k - 1)];
+    emit_entries(d, b.left, j, items, nitems);
+    emit_entries(d, b.right, k - j, items, nitems);
+}
+
+static uint32_t emit_wide(const DpScratch &d, uint32_t n, std::vector<uint32_t> &nodes, uint32_t depth, uint32_t &max_depth)
+{
+    const uint32_t me = (uint32_t)(nodes.size() / 32);
+    nodes.resize(nodes.size() + 32);
+    max_depth = std::max(max_depth, depth + 1);
+    uint32_t items[WIDE_K];
+    int nitems = 0;
+    const BinNode &b = d.bin[n];
+    const int j = d.left_share[(size_t)n * 8];
+    emit_entries(d, b.left, j, items, nitems);
+    emit_entries(d, b.right, (int)WIDE_K - j, items, nitems);
+    for (int i = 0; i < (int)WIDE_K; i++) {
+        uint32_t word[4];
+        if (i >= nitems) { word[0] = word[1] = word[2] = 0x0000FFFFu; word[3] = WIDE_EMPTY; }
+        else {
+            const BinNode &c = d.bin[items[i]];
+            for (int a = 0; a < 3; a++) word[a] = (uint32_t)c.lo[a] | (uint32_t)c.hi[a] << 16;
+            word[3] = (c.left == BIN_LEAF) ? (WIDE_LEAF | c.right) : emit_wide(d, items[i], nodes, depth + 1, max_depth);
+        }
+        memcpy(nodes.data() + (size_t)me * 32 + 4 * i, word, 16);
+    }
+    return me;
+}
+
+static uint32_t build_subtree_dp(Prim *prims, size_t first, size_t count, std::vector<uint32_t> &nodes, uint32_t &max_depth, DpScratch &d)
+{
+    // binary tree, parents before children (an explicit stack: degenerate sets fall back to halving, so the
+    // depth is bounded, but a task holds up to a million triangles)
+    d.bin.clear();
+    d.bin.reserve(2 * count);
+    struct Todo { size_t first, count; uint32_t node; };
+    std::vector<Todo> todo;
+    d.bin.push_back(BinNode());
+    todo.push_back(Todo{first, count, 0});
+    while (!todo.empty()) {
+        Todo t = todo.back(); todo.pop_back();
+        if (t.count == 1) {
+            BinNode &b = d.bin[t.node];
+            const Prim &p = prims[t.first];
+            for (int a = 0; a < 3; a++) { b.lo[a] = p.lo[a]; b.hi[a] = p.hi[a]; }
+            b.left = BIN_LEAF; b.right = (uint32_t)t.first;
+            continue;
+        }
+        const size_t nl = split_serial(prims, t.first, t.count);
+        const uint32_t l = (uint32_t)d.bin.size();
+        d.bin.push_back(BinNode()); d.bin.push_back(BinNode());
+        d.bin[t.node].left = l; d.bin[t.node].right = l + 1;
+        todo.push_back(Todo{t.first + nl, t.count - nl, l + 1});
+        todo.push_back(Todo{t.first, nl, l});
+    }
+    const size_t nb = d.bin.size();
+    d.cost.assign(nb * 8, 0.0f);
+    d.left_share.assign(nb * 8, 0);
+    d.own_node.assign(nb * 8, 0);
+    // children have larger indices than their parents: one backward sweep fills boxes and the table
+    for (size_t n = nb; n-- > 0;) {
+        BinNode &b = d.bin[n];
+        if (b.left == BIN_LEAF) continue;                 // D(leaf, k) = 0
+        const BinNode &l = d.bin[b.left], &r = d.bin[b.right];
+        for (int a = 0; a < 3; a++) { b.lo[a] = std::min(l.lo[a], r.lo[a]); b.hi[a] = std::max(l.hi[a], r.hi[a]); }
+        const float *cl = &d.cost[(size_t)b.left * 8], *cr = &d.cost[(size_t)b.right * 8];
+        float *cn = &d.cost[n * 8];
+        float share[9]; uint8_t share_j[9];
+        for (int k = 2; k <= 8; k++) {
+            float best = 0.0f; int bj = 0;
+            for (int j = 1; j < k; j++) {
+                const float c = cl[j - 1] + cr[k - j - 1];
+                if (bj == 0 || c < best) { best = c; bj = j; }
+            }
+            share[k] = best; share_j[k] = (uint8_t)bj;
+        }
+        const float own = (float)bin_area(b) + share[8];
+        cn[0] = own;
+        d.left_share[n * 8] = share_j[8];
+        d.own_node[n * 8] = 1;
+        for (int k = 2; k <= 8; k++) {
+            if (own <= share[k]) { cn[k - 1] = own; d.own_node[n * 8 + (k - 1)] = 1; d.left_share[n * 8 + (k - 1)] = share_j[8]; }
+            else { cn[k - 1] = share[k]; d.left_share[n * 8 + (k - 1)] = share_j[k]; }
+        }
+    }
+    return emit_wide(d, 0, nodes, 0, max_depth);
+}
+
+static int sah_topology(const uint32_t *ref, uint32_t ntriangles, const std::vector<uint32_t> &leaf_node, WideTree &out, std::string &err, bool collapse_dp)
 {
     // one primitive per triangle that hangs under a reachable leaf, in triangle order (threaded: count, place)
     std::vector<Prim> prims;
@@ -391,11 +511,13 @@ static int sah_topology(const uint32_t *ref, uint32_t ntriangles, const std::vec
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++)
             th.emplace_back([&] {
+                DpScratch scratch;
                 for (;;) {
                     size_t k = next.fetch_add(1);
                     if (k >= ntasks) break;
                     sub[k].reserve((tasks[k].count / 3 + 8) * 32);
-                    build_subtree(prims.data(), tasks[k].first, tasks[k].count, sub[k], 0, sub_depth[k]);
+                    if (collapse_dp) build_subtree_dp(prims.data(), tasks[k].first, tasks[k].count, sub[k], sub_depth[k], scratch);
+                    else build_subtree(prims.data(), tasks[k].first, tasks[k].count, sub[k], 0, sub_depth[k]);
                 }
             });
         for (auto &t : th) t.join();
@@ -522,8 +644,8 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
     phase("reference test order");
     out.tri_to_dev.assign(ntriangles, 0xFFFFFFFFu);
     out.dev_to_tri.clear();
-    if (topology == WIDE_TOPOLOGY_SAH) {
-        if (sah_topology(nodes, ntriangles, leaf_node, out, err) != 0) return -1;
+    if (topology == WIDE_TOPOLOGY_SAH || topology == WIDE_TOPOLOGY_SAH_GREEDY) {
+        if (sah_topology(nodes, ntriangles, leaf_node, out, err, topology == WIDE_TOPOLOGY_SAH) != 0) return -1;
     } else {
     // ---- collapse, one level of wide nodes at a time
     out.dev_to_tri.reserve(ntriangles);
@@ -679,7 +801,9 @@ int validate_wide_tree(const uint32_t *wnodes, size_t nwide, const uint32_t *tri
 int wide_topology_from_env()
 {
     const char *e = getenv("CHROMA_TREE");
-    return (e && !strcmp(e, "collapse")) ? WIDE_TOPOLOGY_COLLAPSE : WIDE_TOPOLOGY_SAH;
+    if (e && !strcmp(e, "collapse")) return WIDE_TOPOLOGY_COLLAPSE;
+    if (e && !strcmp(e, "greedy")) return WIDE_TOPOLOGY_SAH_GREEDY;
+    return WIDE_TOPOLOGY_SAH;
 }
 
 }  // namespace chroma_host

@@ -10,7 +10,8 @@ namespace chroma_host {
 enum : uint32_t { WIDE_K = 8, WIDE_LEAF = 0x80000000u, WIDE_EMPTY = 0xFFFFFFFFu };
 // how the hierarchy above the reference's leaf boxes is chosen
 enum { WIDE_TOPOLOGY_COLLAPSE = 0,     // the reference tree with children pulled up until a node has eight
-       WIDE_TOPOLOGY_SAH = 1 };        // rebuilt with binned surface-area-heuristic splits (default)
+       WIDE_TOPOLOGY_SAH = 1,          // rebuilt with surface-area-heuristic splits, binary tree collapsed to wide nodes at the least total area (default)
+       WIDE_TOPOLOGY_SAH_GREEDY = 2 }; // the same splits, a wide node = a set split greedily until it has eight parts (round 1)
 
 struct WideTree {
     std::vector<uint32_t> wnodes;       // nwide * 8 entries of 4 words: x, y, z boxes, w = child (see above)
@@ -31,7 +32,7 @@ uint32_t wide_stack_need(const uint32_t *wnodes, size_t nwide);
 // Index checks of a wide tree and its record maps (see wide_build.cpp).  Returns 0, or -1 with `err` set.
 int validate_wide_tree(const uint32_t *wnodes, size_t nwide, const uint32_t *tri_to_dev, uint32_t ntriangles,
                        const uint32_t *dev_to_tri, size_t nrecords, std::string &err);
-// CHROMA_TREE=collapse|sah (default sah)
+// CHROMA_TREE=collapse|greedy|sah (default sah)
 int wide_topology_from_env();
 
 }  // namespace chroma_host
