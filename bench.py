@@ -161,8 +161,22 @@ def main():
     ctx = gpu.create_cuda_context(local_rank)
     t0 = time.time()
     gg = gpu.GPUDetector.from_packed(packed)
+    lib_comm = True
     if world > 1:
-        init_comm(ctx)
+        # the library's own RCCL communicator (reductions in place on the device arrays).  Should it not come up on
+        # some rank, ALL ranks agree to reduce through torch.distributed instead (same RCCL, staged through tensors)
+        try:
+            init_comm(ctx)
+            ok = 1
+        except Exception as exc:        # pragma: no cover
+            log('rank %d: library communicator unavailable (%s)' % (rank, exc))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device('cuda', local_rank))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        lib_comm = bool(int(flag.item()))
+        if not lib_comm:
+            ctx._lib.chroma_comm_destroy(ctx.handle)
+            log('reducing the per-channel arrays through torch.distributed')
         remove_published(shm_path, local_rank, dist.barrier)
     elif os.environ.get('CHROMA_BENCH_COMM'):         # one-rank communicator: exercises the RCCL path on a 1-GPU box
         ident = (ctypes.c_uint8 * 128)()
@@ -236,8 +250,12 @@ def main():
         _lib.check(lib.chroma_copy_photon_hits(ctx.handle, gg.handle, 0, nphotons, event.SURFACE_DETECT, ctypes.byref(batch.struct),
                                                ctypes.byref(hits[1]), hits[2].ptr, ctypes.byref(ncopied)))
         # the one exchange: per-channel arrays over RCCL, in place on the device (identity on one GPU)
-        _lib.check(lib.chroma_allreduce_hits(ctx.handle, counts.ptr, earliest.ptr, nch))
-        c, e = counts.get(), earliest.get()
+        if lib_comm:
+            _lib.check(lib.chroma_allreduce_hits(ctx.handle, counts.ptr, earliest.ptr, nch))
+            c, e = counts.get(), earliest.get()
+        else:                           # pragma: no cover
+            from chroma_amd.dist import allreduce_channel_hits
+            c, e = allreduce_channel_hits(counts.get(), earliest.get(), device=torch.device('cuda', local_rank))
         for k, v in st.as_dict().items():
             stats[k] = stats.get(k, 0) + v
         stats['hits'] = stats.get('hits', 0) + int(nhits.value)
@@ -405,7 +423,7 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': RAYCAST_KERNEL, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'hbm_measured_GBps': measured, 'hbm_measured_frac': (measured / HBM_PEAK_GBS) if measured else None,
-                         'limiter': 'dependent-fetch latency at the resident wave count, not bandwidth',
+                         'limiter': 'VALU issue (PMC: SQ_ACTIVE_INST_VALU x 4 = 96 % of the SIMD cycles of the launches), not bandwidth',
                          'algorithmic_bytes_per_launch': ray_bytes_total / ray_launches,
                          'algorithmic_bytes_per_photon_step': ray_bytes_per_step,
                          'launches': int(stats['raycast_launches']), 'avg_launch_ms': avg_launch_ms,
@@ -417,6 +435,7 @@ def main():
         }
         print(json.dumps(result), flush=True)
     if world > 1:
+        ctx._lib.chroma_comm_destroy(ctx.handle)       # (before torch tears its own communicator down)
         dist.destroy_process_group()
 
 
