@@ -908,7 +908,11 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #ifndef QUAD_STACK
 #define QUAD_STACK COOP_STACK    // (node, distance) entries per ray in LDS
 #endif
-#define QUAD_STRIDE (2 * QUAD_STACK + QUAD_PENDING + 1)     // words per ray, +1 staggers the banks
+#ifndef QUAD_SIGNED_SLABS
+#define QUAD_SIGNED_SLABS 1  // near/far faces by the sign of the direction (box_interval_signed); origin and direction of a ray then
+#endif                       // live in LDS between its triangle rounds (the three shift registers have to come from somewhere)
+#define QUAD_OD_WORDS (QUAD_SIGNED_SLABS ? 6 : 0)
+#define QUAD_STRIDE (2 * QUAD_STACK + QUAD_PENDING + QUAD_OD_WORDS + 1)     // words per ray, odd: staggers the banks
 #ifndef QUAD_REFILL_MIN
 #define QUAD_REFILL_MIN 4    // refill once this many of the 16 rays are done
 #endif
@@ -969,6 +973,25 @@ __device__ inline void box_interval_pk(float ax, float ay, float az, f32x2 bx, f
     tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)),
                            __builtin_fmaxf(tz.x, tz.y));
 }
+// The same test with the faces picked by the SIGN of the direction instead of by min/max: the packed bounds of an
+// axis the ray runs down are rotated by 16 bits (one v_alignbit with a per-ray shift), so that the low half always
+// is the face the ray meets first.  near = fma(q_near, a, b - |a|), far = fma(q_far, a, b + |a|) are the very values
+// min and max picked (fma and the offsets are monotone), so the result is bit-identical for a real box -- and an EMPTY
+// entry (lo = 0xFFFF, hi = 0 on every axis) now fails by itself, because nothing swaps its faces back.
+__device__ inline void box_interval_signed(float ax, float ay, float az, uint32_t sx, uint32_t sy, uint32_t sz,
+                                           f32x2 bx, f32x2 by, f32x2 bz, uint4 nd, float &tmin, float &tmax)
+{
+    const uint32_t x = __builtin_amdgcn_alignbit(nd.x, nd.x, sx), y = __builtin_amdgcn_alignbit(nd.y, nd.y, sy),
+                   z = __builtin_amdgcn_alignbit(nd.z, nd.z, sz);
+    f32x2 qx = {(float)(x & 0xFFFFu), (float)(x >> 16)};
+    f32x2 qy = {(float)(y & 0xFFFFu), (float)(y >> 16)};
+    f32x2 qz = {(float)(z & 0xFFFFu), (float)(z >> 16)};
+    const f32x2 tx = __builtin_elementwise_fma(qx, (f32x2){ax, ax}, bx);
+    const f32x2 ty = __builtin_elementwise_fma(qy, (f32x2){ay, ay}, by);
+    const f32x2 tz = __builtin_elementwise_fma(qz, (f32x2){az, az}, bz);
+    tmin = __builtin_fmaxf(__builtin_fmaxf(tx.x, ty.x), __builtin_fmaxf(tz.x, 0.0f));
+    tmax = __builtin_fminf(__builtin_fminf(tx.y, ty.y), tz.y);
+}
 __device__ inline uint32_t quad_or_u32(uint32_t v)
 {
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
@@ -1004,14 +1027,20 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     // per-ray state, identical in the 4 lanes of a quad
     bool has_ray = false, active = false;
     int slot = 0;
+#if QUAD_SIGNED_SLABS
+    float *ray_od = (float *)(stack_n + 2 * QUAD_STACK + QUAD_PENDING);      // origin, direction of this quad's ray
+#else
     v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
+#endif
     float rax = 0.f, ray_ = 0.f, raz = 0.f; // RayFast::a (three scalars: as a struct it ended up in LDS), and {blo, bhi} per axis
     f32x2 rbx = {0.f, 0.f}, rby = {0.f, 0.f}, rbz = {0.f, 0.f};
+#if QUAD_SIGNED_SLABS
+    uint32_t rsx = 0, rsy = 0, rsz = 0;     // 16 for an axis the ray runs down (box_interval_signed)
+#endif
     uint32_t last_hit_w = WIDE_NONE;        // the leaf word of the photon's last hit (never entered)
     int triangle_index = -1;
     uint32_t best_rank = 0;
-    float min_distance = -1.0f;
-    float prune_t = cm_inff();              // min_distance, or +inf while nothing was hit
+    float prune_t = cm_inff();              // distance of the best hit, +inf while nothing was hit
     uint32_t cur = WIDE_NONE;
     int sp = 0, npend = 0;
     uint32_t phead = 0;                     // first postponed triangle in the ring
@@ -1050,15 +1079,24 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 const float4 r0 = r[0], r1 = r[1];
                 if (__float_as_int(r1.w) == 0) {                 // (other slots were settled by k_ray_setup)
                     const float4 r2 = r[2], r3 = r[3];
+#if QUAD_SIGNED_SLABS
+                    if (j == 0) { ray_od[0] = r0.x; ray_od[1] = r0.y; ray_od[2] = r0.z; ray_od[3] = r1.x; ray_od[4] = r1.y; ray_od[5] = r1.z; }
+#else
                     origin = mk3(r0.x, r0.y, r0.z);
                     direction = mk3(r1.x, r1.y, r1.z);
+#endif
                     { const int lh = __float_as_int(r0.w); last_hit_w = lh >= 0 ? (0x80000000u | (uint32_t)lh) : WIDE_NONE; }
                     rax = r2.x; ray_ = r2.y; raz = r2.z;
+#if QUAD_SIGNED_SLABS
+                    { const float mx = cm_fabsf(rax), my = cm_fabsf(ray_), mz = cm_fabsf(raz);
+                      rbx = (f32x2){r3.x - mx, r3.x + mx}; rby = (f32x2){r3.y - my, r3.y + my}; rbz = (f32x2){r3.z - mz, r3.z + mz}; }
+                    rsx = rax < 0.f ? 16u : 0u; rsy = ray_ < 0.f ? 16u : 0u; rsz = raz < 0.f ? 16u : 0u;
+#else
                     rbx = (f32x2){r3.x - rax, r3.x + rax};
                     rby = (f32x2){r3.y - ray_, r3.y + ray_};
                     rbz = (f32x2){r3.z - raz, r3.z + raz};
+#endif
                     triangle_index = -1;
-                    min_distance = -1.0f;
                     prune_t = cm_inff();
                     sp = 0;
                     npend = 0;
@@ -1136,11 +1174,18 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #endif
                 if (COUNT && j == 0) cnt.nodes += 8;
                 float ta, tb, fa, fb;
+#if QUAD_SIGNED_SLABS
+                box_interval_signed(rax, ray_, raz, rsx, rsy, rsz, rbx, rby, rbz, ea, ta, fa);
+                box_interval_signed(rax, ray_, raz, rsx, rsy, rsz, rbx, rby, rbz, eb, tb, fb);
+                const bool pa = !(ta > fa) & !(ta > prune_t);        // (an empty entry fails the first test by itself)
+                const bool pb = !(tb > fb) & !(tb > prune_t);
+#else
                 box_interval_pk(rax, ray_, raz, rbx, rby, rbz, ea, ta, fa);
                 box_interval_pk(rax, ray_, raz, rbx, rby, rbz, eb, tb, fb);
                 // intersect_node (mesh.h:16-34) with prune_t = +inf until something is hit
                 const bool pa = (ea.w != WIDE_NONE) & !(ta > fa) & !(ta > prune_t);
                 const bool pb = (eb.w != WIDE_NONE) & !(tb > fb) & !(tb > prune_t);
+#endif
                 const bool la = pa & ((int)ea.w < 0) & (ea.w != last_hit_w);
                 const bool lb = pb & ((int)eb.w < 0) & (eb.w != last_hit_w);
                 const bool ia = pa & ((int)ea.w >= 0), ib = pb & ((int)eb.w >= 0);
@@ -1221,6 +1266,9 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     if (COUNT) cnt.tris++;
                     const float4 *tp = g.tri + TRI_STRIDE * (size_t)tri;
                     float4 a = tp[0], b = tp[1], c = tp[2];
+#if QUAD_SIGNED_SLABS
+                    const v3 origin = mk3(ray_od[0], ray_od[1], ray_od[2]), direction = mk3(ray_od[3], ray_od[4], ray_od[5]);
+#endif
                     hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
                     rank = __float_as_uint(c.w);
                 }
@@ -1230,10 +1278,9 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 const bool cand = hit && dkey == dmin;
                 const uint32_t rm = quad_min_u32(cand ? rank : 0xFFFFFFFFu);
                 const uint32_t wtri = quad_max_u32((cand && rank == rm) ? tri + 1u : 0u) - 1u;
-                const bool better = dmin != 0x7F800000u &&
-                                    (triangle_index == -1 || dm < min_distance || (dm == min_distance && rm < best_rank));
+                // (prune_t is the best distance, +inf before the first hit: no separate "nothing yet" test)
+                const bool better = dmin != 0x7F800000u && (dm < prune_t || (dm == prune_t && rm < best_rank));
                 triangle_index = better ? (int)wtri : triangle_index;
-                min_distance = better ? dm : min_distance;
                 prune_t = better ? dm : prune_t;
                 best_rank = better ? rm : best_rank;
                 phead = (phead + (uint32_t)take) & (QUAD_PENDING - 1u);
@@ -1250,6 +1297,9 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     if (COUNT) cnt.tris++;
                     const float4 *tp = g.tri + TRI_STRIDE * (size_t)tri;
                     float4 a = tp[0], b = tp[1], c = tp[2];
+#if QUAD_SIGNED_SLABS
+                    const v3 origin = mk3(ray_od[0], ray_od[1], ray_od[2]), direction = mk3(ray_od[3], ray_od[4], ray_od[5]);
+#endif
                     hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
                     rank = __float_as_uint(c.w);
                 }
@@ -1261,9 +1311,8 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     const bool cand = hit && dkey == dmin;
                     const uint32_t rm = quad_min_u32(cand ? rank : 0xFFFFFFFFu);
                     const uint32_t wtri = quad_max_u32((cand && rank == rm) ? tri + 1u : 0u) - 1u;
-                    if (triangle_index == -1 || dm < min_distance || (dm == min_distance && rm < best_rank)) {
+                    if (dm < prune_t || (dm == prune_t && rm < best_rank)) {
                         triangle_index = (int)wtri;
-                        min_distance = dm;
                         prune_t = dm;
                         best_rank = rm;
                     }
@@ -1282,7 +1331,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
         if (has_ray && !active) {
             if (j == 0) {
                 hit_triangle[slot] = triangle_index;                 // record index, or a HIT_* code
-                hit_distance[slot] = min_distance;
+                hit_distance[slot] = triangle_index == -1 ? -1.0f : prune_t;
                 if (triangle_index == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
             }
             has_ray = false;
