@@ -1015,9 +1015,10 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     const unsigned lane = lane_id();
     const unsigned j = lane & 3u, gshift = lane & ~3u, grp = lane >> 2;
     // what the 4 lanes of a quad decide about their 8 entries travels as ONE word, OR-ed across the quad
-    // by two DPP steps: bit j of nibble 0/1 = lane j's first/second entry is a leaf to test, of nibble
-    // 2/3 = it is an inner node to visit.  (Wave ballots cost two VALU operations each plus the extract.)
-    const uint32_t jbit = 1u << j, below2 = (jbit - 1u) * 0x11u;
+    // by two DPP steps: bit 2j / 2j+1 of byte 0 = lane j's first / second entry is a leaf to test, of byte 1 =
+    // it is an inner node to visit.  (Wave ballots cost two VALU operations each plus the extract.)
+    // (entry e of lane j is bit 2j+e: the entries of a node in memory order)
+    const uint32_t jbit = 1u << (2u * j), below2 = jbit - 1u;       // (below2: the entries of lower lanes, within a byte)
     uint32_t *stack_n = s_lds + grp * QUAD_STRIDE;
     float *stack_t = (float *)(stack_n + QUAD_STACK);
     uint32_t *pending = stack_n + 2 * QUAD_STACK;
@@ -1117,7 +1118,8 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #endif
         // ---- node phase: every active quad visits one node per iteration
         more = !exhausted || loc_next < loc_end;
-        const int stop_at = more ? max(0, (int)__popcll(__ballot(active && j == 0)) - (int)QUAD_REFILL_MIN) : 0;
+        // (one lane per quad counts: masks and counts stay in scalar registers)
+        const int stop_at = more ? max(0, (int)__popcll(__ballot(active) & 0x1111111111111111ull) - (int)QUAD_REFILL_MIN) : 0;
         do {
 #if QUAD_TIMING
             TQ_STAMP(tq_a); tq_iters++; tq_active += (unsigned)__popcll(__ballot(active && j == 0));
@@ -1186,11 +1188,12 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 const bool pa = (ea.w != WIDE_NONE) & !(ta > fa) & !(ta > prune_t);
                 const bool pb = (eb.w != WIDE_NONE) & !(tb > fb) & !(tb > prune_t);
 #endif
-                const bool la = pa & ((int)ea.w < 0) & (ea.w != last_hit_w);
-                const bool lb = pb & ((int)eb.w < 0) & (eb.w != last_hit_w);
-                const bool ia = pa & ((int)ea.w >= 0), ib = pb & ((int)eb.w >= 0);
-                const uint32_t qm = quad_or_u32((((((ib ? jbit : 0u) << 4) | (ia ? jbit : 0u)) << 4 | (lb ? jbit : 0u)) << 4) |
-                                                (la ? jbit : 0u));
+                // (the photon's last hit is left out when its turn to be tested comes: one compare per triangle
+                //  round instead of two per visit)
+                const bool fa_leaf = (int)ea.w < 0, fb_leaf = (int)eb.w < 0;
+                const bool la = pa & fa_leaf, lb = pb & fb_leaf;
+                const bool ia = pa & !fa_leaf, ib = pb & !fb_leaf;
+                const uint32_t qm = quad_or_u32((((ib ? 2u * jbit : 0u) | (ia ? jbit : 0u)) << 8) | (lb ? 2u * jbit : 0u) | (la ? jbit : 0u));
                 // postponed triangles: ring slots after the ones already there, lower lanes first
                 {
                     uint32_t off = phead + (uint32_t)npend + __popc(qm & below2);
@@ -1199,7 +1202,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     npend += __popc(qm & 0xFFu);
                 }
                 cur = WIDE_NONE;
-                const uint32_t mi = qm >> 8;                 // inner entries: nibble 0 = first, nibble 1 = second entries
+                const uint32_t mi = qm >> 8;                 // inner entries, bit = entry number
                 if (mi) {
                     // nearest inner child: smallest (distance, entry) key -- the entry number replaces
                     // the low 3 mantissa bits, which only matters for the ORDER of the visits
@@ -1210,7 +1213,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     cur = quad_max_u32(na ? ea.w : (nb ? eb.w : 0u));
                     // every other inner child goes on the stack at its own slot
                     const bool qa = ia && !na, qb = ib && !nb;
-                    const uint32_t mo = mi & ~(1u << ((ne >> 1) | ((ne & 1u) << 2)));
+                    const uint32_t mo = mi & ~(1u << ne);
                     int pos = sp + __popc(mo & below2);
                     sp += __popc(mo);
 #if QUAD_UNIFORM_SPILL
@@ -1240,7 +1243,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #if QUAD_TIMING
             TQ_STAMP(tq_b); tq_node += tq_b - tq_a;       // (a_ = after the wait when the wave fetched, else the pop stamp)
 #endif
-        } while (!__any(npend >= QUAD_FLUSH) && __popcll(__ballot(active && j == 0)) > stop_at &&
+        } while (!__any(npend >= QUAD_FLUSH) && (int)__popcll(__ballot(active) & 0x1111111111111111ull) > stop_at &&
                  !(QUAD_TRIGGER_LANES && (int)__popcll(__ballot((int)j < npend)) >= QUAD_TRIGGER_LANES));
         __builtin_amdgcn_wave_barrier();      // (scheduling fence: the lanes of a quad exchange data through LDS)
 #if QUAD_TIMING
@@ -1261,8 +1264,8 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 bool hit = false;
                 float distance = 0.0f;
                 uint32_t tri = 0, rank = 0xFFFFFFFFu;
-                if ((int)j < take) {
-                    tri = pending[(phead + j) & (QUAD_PENDING - 1u)];
+                if ((int)j < take) tri = pending[(phead + j) & (QUAD_PENDING - 1u)];
+                if ((int)j < take && (0x80000000u | tri) != last_hit_w) {
                     if (COUNT) cnt.tris++;
                     const float4 *tp = g.tri + TRI_STRIDE * (size_t)tri;
                     float4 a = tp[0], b = tp[1], c = tp[2];
@@ -1292,8 +1295,8 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 bool hit = false;
                 float distance = 0.0f;
                 uint32_t tri = 0, rank = 0xFFFFFFFFu;
-                if ((int)j < take) {
-                    tri = pending[(phead + j) & (QUAD_PENDING - 1u)];
+                if ((int)j < take) tri = pending[(phead + j) & (QUAD_PENDING - 1u)];
+                if ((int)j < take && (0x80000000u | tri) != last_hit_w) {
                     if (COUNT) cnt.tris++;
                     const float4 *tp = g.tri + TRI_STRIDE * (size_t)tri;
                     float4 a = tp[0], b = tp[1], c = tp[2];
