@@ -1067,7 +1067,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
             if (loc_next >= loc_end) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(work_counter, (uint32_t)chunk);
-                base = __shfl(base, 0);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);       // (wave-uniform from here: scalar registers)
                 if (base + (uint32_t)chunk >= (uint32_t)nthreads) exhausted = true;
                 loc_next = min(base, (uint32_t)nthreads);
                 loc_end = min(base + (uint32_t)chunk, (uint32_t)nthreads);

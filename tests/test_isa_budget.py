@@ -32,9 +32,10 @@ def test_ray_cast_kernels_hold_their_state_in_registers(isa_table):
     # the counting build (untimed: one pass per bench run, and the parity tests) may keep a few words in scratch
     k = isa_table['k_raycast_quad<true>']
     assert k['scratch'] <= 32 and k['waves'] == 7, k
-    # exactly the 16 per-ray areas: a struct the compiler cannot keep in registers is "promoted" to LDS silently
+    # exactly the 16 per-ray areas (24 stack entries of two words, a ring of 16 postponed triangles, origin and
+    # direction, one word of padding): a struct the compiler cannot keep in registers is "promoted" to LDS silently
     # (768 bytes per wave until RayFast::a became three scalars)
-    assert isa_table['k_raycast_quad<false>']['lds'] == 16 * (2 * 24 + 16 + 1) * 4
+    assert isa_table['k_raycast_quad<false>']['lds'] == 16 * (2 * 24 + 16 + 6 + 1) * 4
     k = isa_table['k_raycast_pair<false>']
     assert k['scratch'] == 0 and k['waves'] == 5 and k['lds'] == 32 * (2 * 18 + 16 + 2) * 4, k
 
