@@ -31,7 +31,7 @@ def run(name, geo):
         pn, pb = c_void_p(), c_void_p()
         lib.chroma_bvh_data(handle, ctypes.byref(pn), ctypes.byref(pb))
         nodes = np.array((ctypes.c_uint32 * (4 * nnodes.value)).from_address(pn.value), dtype=np.uint32).reshape(-1, 4)
-        for topo in ('sah', 'collapse'):
+        for topo in ('sah', 'greedy', 'collapse'):
             os.environ['CHROMA_TREE'] = topo
             wh, nw, nr, dp = c_void_p(), c_uint64(), c_uint64(), c_uint32()
             rc = lib.chroma_wide_build(ptr(nodes), c_uint64(len(nodes)), c_uint32(len(t)), ctypes.byref(wh), ctypes.byref(nw), ctypes.byref(nr), ctypes.byref(dp))
