@@ -65,7 +65,8 @@ struct chroma_ctx {
     int32_t *hit_triangle = nullptr;
     float *hit_distance = nullptr;
     uint32_t *retry_list = nullptr;        // [capacity] queue slots handed to k_raycast_retry
-    float4 *rays = nullptr;                // [capacity][4] ray records (k_ray_setup)
+    float4 *rays = nullptr;                // [capacity][4] ray records (k_ray_setup / k_load_working / k_physics)
+    float4 *rays_b = nullptr;              // the records of the NEXT step while k_physics writes them (default walk)
     float4 *work_a = nullptr, *work_b = nullptr;    // [capacity][4] the dense working sets that go with queue_a / queue_b
     // small device scratch: [0..3] DeviceCounters, then misc words
     DeviceCounters *d_counters = nullptr;
@@ -251,6 +252,40 @@ __global__ void k_step_begin(const uint32_t *in_queue, uint32_t *out_queue, Step
 // {a = scale/d}, {b = (world_origin - o)/d} (RayFast: blo = b - a, bhi = b + a).  Status 0 = cast; the
 // other slots (NaN, 1/d not moderate) get their hit entry -- and their place in the retry list -- right
 // here.  The photon comes from the dense working set (see k_load_working).
+// the record of one ray at `r`; returns its status (0 = cast, HIT_NAN, HIT_RETRY)
+__device__ inline int make_ray_record(const GeoView &g, float4 *r, v3 origin, v3 direction, int renorm, int last_hit)
+{
+    int status;
+    v3 a = mk3(0.f, 0.f, 0.f), b = mk3(0.f, 0.f, 0.f);
+    if (renorm) direction = direction / norm(direction);
+    if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
+        status = HIT_NAN;
+    } else {
+        v3 noid = (-origin) / direction;
+        v3 inv_dir = 1.0f / direction;
+        bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                        cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+        if (!moderate) {
+            status = HIT_RETRY;
+        } else {
+            a = ray_fast(g, noid, inv_dir).a;
+            // b exactly as ray_fast forms it (blo = b - a, bhi = b + a are rebuilt by the kernels)
+            b = mk3(cm_fmaf(g.world_origin[0], inv_dir.x, noid.x), cm_fmaf(g.world_origin[1], inv_dir.y, noid.y),
+                    cm_fmaf(g.world_origin[2], inv_dir.z, noid.z));
+            status = 0;
+        }
+    }
+    r[0] = make_float4(origin.x, origin.y, origin.z, __int_as_float(last_hit));
+    r[1] = make_float4(direction.x, direction.y, direction.z, __int_as_float(status));
+    r[2] = make_float4(a.x, a.y, a.z, 0.0f);
+    r[3] = make_float4(b.x, b.y, b.z, 0.0f);
+    return status;
+}
+
+// With the default walk this kernel does not run at all (round 2): k_load_working writes the records of the first
+// step, k_physics those of every later one -- the photon is in their registers anyway, the launch policy of the next
+// step is known (re-normalise unless the reference's last launch has begun: StepState::in_tail) -- and k_raycast_quad
+// settles the few slots whose status is not 0 when it meets them (`settle`).  The cross-check walks keep it.
 __global__ __launch_bounds__(256) void
 k_ray_setup(GeoView g, const float4 *work, const StepState *st, float4 *rays,
             int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint32_t *retry_counter)
@@ -259,32 +294,8 @@ k_ray_setup(GeoView g, const float4 *work, const StepState *st, float4 *rays,
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < nthreads; slot += gridDim.x * blockDim.x) {
         const float4 *w = work + 4 * (size_t)slot;
         const float4 w0 = w[0], w1 = w[1], w3 = w[3];
-        int status;
-        v3 origin = mk3(w0.x, w0.y, w0.z), direction = mk3(w1.x, w1.y, w1.z), a = mk3(0.f, 0.f, 0.f), b = mk3(0.f, 0.f, 0.f);
-        const int last_hit = __float_as_int(w3.z);
-        if (renorm) direction = direction / norm(direction);
-        if (cm_isnan(direction.x * direction.y * direction.z * origin.x * origin.y * origin.z)) {
-            status = HIT_NAN;
-        } else {
-            v3 noid = (-origin) / direction;
-            v3 inv_dir = 1.0f / direction;
-            bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
-                            cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
-            if (!moderate) {
-                status = HIT_RETRY;
-            } else {
-                a = ray_fast(g, noid, inv_dir).a;
-                // b exactly as ray_fast forms it (blo = b - a, bhi = b + a are rebuilt by the kernels)
-                b = mk3(cm_fmaf(g.world_origin[0], inv_dir.x, noid.x), cm_fmaf(g.world_origin[1], inv_dir.y, noid.y),
-                        cm_fmaf(g.world_origin[2], inv_dir.z, noid.z));
-                status = 0;
-            }
-        }
-        float4 *r = rays + 4 * (size_t)slot;
-        r[0] = make_float4(origin.x, origin.y, origin.z, __int_as_float(last_hit));
-        r[1] = make_float4(direction.x, direction.y, direction.z, __int_as_float(status));
-        r[2] = make_float4(a.x, a.y, a.z, 0.0f);
-        r[3] = make_float4(b.x, b.y, b.z, 0.0f);
+        const int status = make_ray_record(g, rays + 4 * (size_t)slot, mk3(w0.x, w0.y, w0.z), mk3(w1.x, w1.y, w1.z), renorm,
+                                           __float_as_int(w3.z));
         if (status != 0) {
             hit_triangle[slot] = status;
             hit_distance[slot] = 0.0f;
@@ -1003,8 +1014,9 @@ template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD_WAVES_PER_EU, QUAD_WAVES_PER_EU))) void
 k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint2 *spill_base, DeviceCounters *counters,
-               int big_chunk)
+               int big_chunk, int settle)
 {
+    // (`settle`: nobody has written the hit entries of the slots whose ray record says "not to be cast" yet)
     const int nthreads = (int)st->n;
     if ((long long)blockIdx.x * 16 >= nthreads) return;
     uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
@@ -1105,6 +1117,11 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     cur = 0;
                     has_ray = true;
                     active = true;
+                } else if (settle && j == 0) {
+                    const int status = __float_as_int(r1.w);             // HIT_NAN, or HIT_RETRY: 1/d not moderate
+                    hit_triangle[slot] = status;
+                    hit_distance[slot] = 0.0f;
+                    if (status == HIT_RETRY) retry_list[atomicAdd(retry_counter, 1u)] = (uint32_t)slot;
                 }
             }
         }
@@ -1938,7 +1955,7 @@ template <bool FULL>
 __global__ __launch_bounds__(PHYS_BLOCK) __attribute__((amdgpu_waves_per_eu(FULL ? PHYS_WAVES_PER_EU : PHYS_PLAIN_WAVES_PER_EU))) void
 k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32_t *output_queue, float4 *work_out,
           const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base,
-          int use_weights, int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters)
+          int use_weights, int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters, float4 *rays_next)
 {
     // Two passes per step.  Main pass (fixup = 0): every slot of the working set; a slot the ray cast
     // handed to the strict walk (HIT_RETRY) is left alone, and so is a hit that is not REGULAR
@@ -1955,7 +1972,7 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
     __shared__ uint32_t s_class_count[PHYS_BLOCK / WAVE][PHYS_CLASSES];
     __shared__ int32_t s_perm[PHYS_BLOCK];
 #endif
-    const int nthreads = fixup ? (int)st->retry : (int)st->n, renorm = (int)st->renorm;
+    const int nthreads = fixup ? (int)st->retry : (int)st->n, renorm = (int)st->renorm, renorm_next = st->in_tail ? 0 : 1;
     unsigned long long nsteps = 0;
     // the grid is sized for an upper bound of the photon count: blocks stride over the slots
     for (int block_base = blockIdx.x * PHYS_BLOCK; block_base < nthreads; block_base += gridDim.x * PHYS_BLOCK) {
@@ -2081,6 +2098,9 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
         w[1] = make_float4(p.direction.x, p.direction.y, p.direction.z, p.time);
         w[2] = make_float4(p.polarization.x, p.polarization.y, p.polarization.z, p.weight);
         w[3] = make_float4(__uint_as_float(p.history), __uint_as_float(counter), __int_as_float(last_hit_record), __uint_as_float(photon_id));
+        // the survivor's ray for the next step (see k_ray_setup): the next launch re-normalises unless the reference's
+        // last launch has begun -- which k_step_begin of THIS step has already decided
+        if (rays_next) make_ray_record(g, rays_next + 4 * (size_t)(at - 1u), p.position, p.direction, renorm_next, last_hit_record);
     }
     __syncthreads();        // s_counts is reused by the next round
     }
@@ -2101,8 +2121,9 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
 // ncopies clones of a photon next to each other); photons that are already terminal are left out -- and
 // thereby untouched (propagate.cu:258).
 __global__ __launch_bounds__(PHYS_BLOCK) void
-k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t n, uint32_t ncopies, uint32_t true_n)
+k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t n, uint32_t ncopies, uint32_t true_n, float4 *rays)
 {
+    // (`rays`: also the ray records of the first step -- the first launch of a call always re-normalises)
     __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
     for (uint64_t block_base = (uint64_t)blockIdx.x * PHYS_BLOCK; block_base < n; block_base += (uint64_t)gridDim.x * PHYS_BLOCK) {
         uint64_t j = block_base + threadIdx.x;
@@ -2123,6 +2144,7 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
             w[1] = make_float4(dir.x, dir.y, dir.z, pv.t[photon_id]);
             w[2] = make_float4(pol.x, pol.y, pol.z, pv.weights[photon_id]);
             w[3] = make_float4(__uint_as_float(flags), __uint_as_float(pv.rng_counters[photon_id]), __int_as_float(lh), __uint_as_float(photon_id));
+            if (rays) make_ray_record(g, rays + 4 * (size_t)(at - 1u), pos, dir, 1, lh);
         }
         __syncthreads();
     }
@@ -2714,9 +2736,18 @@ static size_t spill_entries(const chroma_ctx *ctx)
 // `n_upper` bounds the count and sizes the grids; `in_q`/`out_q` are whole queues (slot 0 = tail) and
 // `work_in`/`work_out` the working sets that go with them.  With `ev` (4 events): [0] step start,
 // [3] ray-cast kernel start, [1] its end, [2] step end.
+// The walk whose steps chain their ray records from kernel to kernel (k_load_working -> k_raycast_quad -> k_physics ->
+// k_raycast_quad ...) instead of running k_ray_setup: the default one.
+static bool step_uses_quad_walk(const chroma_ctx *ctx, const chroma_geometry *geom)
+{
+    return geom->view.wnodes != nullptr && ctx->wide_walk == CHROMA_WALK_QUAD && geom->wide_stack_need <= QUAD_STACK + COOP_SPILL;
+}
+
+// `rays_ready`: the records of this step are in ctx->rays already (written by k_load_working or by the k_physics of
+// the step before).  With the default walk the records of the next step go to ctx->rays_b, and the two are swapped.
 static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, long long n_upper, const uint32_t *in_q,
                              uint32_t *out_q, const float4 *work_in, float4 *work_out, chroma_rng rng, int use_weights,
-                             int scatter_first, hipEvent_t *ev = nullptr, uint32_t first_n = 0)
+                             int scatter_first, hipEvent_t *ev = nullptr, uint32_t first_n = 0, bool rays_ready = false)
 {
     if (n_upper <= 0) return CHROMA_OK;
     uint32_t need = geom->stack_need;
@@ -2749,11 +2780,14 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st,
                        use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8), first_n);
     if (ev) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-    {
+    const bool chained = quad && step_uses_quad_walk(ctx, geom);
+    if (!(chained && rays_ready)) {
         unsigned sblocks = (unsigned)std::min<long long>((n_upper + 255) / 256, (long long)ctx->physics_blocks * 4);
         hipLaunchKernelGGL(k_ray_setup, dim3(sblocks), dim3(256), 0, ctx->stream, geom->view, work_in, st, ctx->rays,
                            ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, &st->retry);
     }
+    const int settle = (chained && rays_ready) ? 1 : 0;
+    float4 *rays_next = chained ? ctx->rays_b : nullptr;
     if (ev) HIP_TRY(hipEventRecord(ev[3], ctx->stream));        // the ray-cast kernel proper is timed from here
 #define RAYCAST_LAUNCH(COUNT)                                                                                          \
     do {                                                                                                               \
@@ -2762,7 +2796,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
         else if (quad)                                                                                                 \
             hipLaunchKernelGGL((k_raycast_quad<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
-                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
+                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, settle); \
         else if (coop)                                                                                                 \
             hipLaunchKernelGGL((k_raycast_coop<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
@@ -2783,11 +2817,11 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (plain)
         hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                            ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                           ctx->retry_list, 0, pc);
+                           ctx->retry_list, 0, pc, rays_next);
     else
         hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                            ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                           ctx->retry_list, 0, pc);
+                           ctx->retry_list, 0, pc, rays_next);
     // (both passes stride over the list and leave at once when it is short -- the usual case -- but a plain geometry
     //  with faces on the world box lists a good part of its hits for the exact check: grids for that)
     const unsigned rblocks = (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK, 8 * 256);
@@ -2800,13 +2834,14 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (plain)
         hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
                            work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
-                           scatter_first, ctx->retry_list, 1, pc);
+                           scatter_first, ctx->retry_list, 1, pc, rays_next);
     else
         hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
                            work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
-                           scatter_first, ctx->retry_list, 1, pc);
+                           scatter_first, ctx->retry_list, 1, pc, rays_next);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(hipGetLastError());
+    if (chained) std::swap(ctx->rays, ctx->rays_b);       // (what k_physics wrote is the next step's input)
     return CHROMA_OK;
 }
 
@@ -3060,6 +3095,7 @@ int chroma_shutdown(chroma_ctx *ctx)
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
     if (ctx->retry_list) hipFree(ctx->retry_list);
     if (ctx->rays) hipFree(ctx->rays);
+    if (ctx->rays_b) hipFree(ctx->rays_b);
     if (ctx->work_a) hipFree(ctx->work_a);
     if (ctx->work_b) hipFree(ctx->work_b);
     hipFree(ctx->d_counters);
@@ -3586,10 +3622,10 @@ static int distance_to_mesh_fast(chroma_ctx *ctx, chroma_geometry *geom, int32_t
     const unsigned waves = (unsigned)std::min<long long>(((long long)n + 15) / 16, (long long)ctx->quad_waves);
     if (ctx->counting)
         hipLaunchKernelGGL((k_raycast_quad<true>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, 0, st,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk);
+                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, 0);
     else
         hipLaunchKernelGGL((k_raycast_quad<false>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, 0, st,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk);
+                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, 0);
     hipLaunchKernelGGL(k_distance_finish, dim3(blocks), dim3(256), 0, ctx->stream, geom->view, (int)n, ctx->rays, ctx->hit_triangle,
                        ctx->hit_distance, d_distance, d_triangle, ctx->retry_list, st);
     if (ctx->counting)
@@ -3613,12 +3649,14 @@ static int ensure_queues(chroma_ctx *ctx, size_t n)
     if (ctx->hit_distance) hipFree(ctx->hit_distance);
     if (ctx->retry_list) hipFree(ctx->retry_list);
     if (ctx->rays) hipFree(ctx->rays);
+    if (ctx->rays_b) hipFree(ctx->rays_b);
     if (ctx->work_a) hipFree(ctx->work_a);
     if (ctx->work_b) hipFree(ctx->work_b);
     ctx->work_a = ctx->work_b = nullptr;
     ctx->queue_a = ctx->queue_b = nullptr;
     ctx->hit_triangle = nullptr; ctx->hit_distance = nullptr; ctx->retry_list = nullptr;
     ctx->rays = nullptr;
+    ctx->rays_b = nullptr;
     ctx->queue_capacity = 0;
     HIP_TRY(hipMalloc((void **)&ctx->queue_a, (n + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->queue_b, (n + 1) * sizeof(uint32_t)));
@@ -3626,6 +3664,7 @@ static int ensure_queues(chroma_ctx *ctx, size_t n)
     HIP_TRY(hipMalloc((void **)&ctx->hit_distance, (n + 1) * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&ctx->retry_list, (n + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->rays, (n + 1) * 4 * sizeof(float4)));
+    HIP_TRY(hipMalloc((void **)&ctx->rays_b, (n + 1) * 4 * sizeof(float4)));
     HIP_TRY(hipMalloc((void **)&ctx->work_a, (n + 1) * 4 * sizeof(float4)));
     HIP_TRY(hipMalloc((void **)&ctx->work_b, (n + 1) * 4 * sizeof(float4)));
     ctx->queue_capacity = n + 1;
@@ -3709,7 +3748,8 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         {
             unsigned blocks = (unsigned)std::min<uint64_t>((nphotons + PHYS_BLOCK - 1) / PHYS_BLOCK, (uint64_t)ctx->physics_blocks);
             hipLaunchKernelGGL(k_load_working, dim3(blocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, in_q, work_in,
-                               (uint64_t)nphotons, ncopies, (uint32_t)(nphotons / ncopies));
+                               (uint64_t)nphotons, ncopies, (uint32_t)(nphotons / ncopies),
+                               step_uses_quad_walk(ctx, geom) ? ctx->rays : nullptr);
         }
         HIP_TRY(hipGetLastError());
         const int nev = time_kernels ? 4 * max_steps : 0;
@@ -3738,7 +3778,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
             }
             rc = launch_split_step(ctx, geom, pv, n_upper, in_q, out_q, work_in, work_out, rng, use_weights,
                                    step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 4 * step : nullptr,
-                                   step == 0 ? (uint32_t)nphotons : 0u);
+                                   step == 0 ? (uint32_t)nphotons : 0u, step_uses_quad_walk(ctx, geom));
             if (rc) return rc;
             if (time_kernels) steps_timed = step + 1;
             step++;
