@@ -529,6 +529,31 @@ def test_edge_inputs_in_a_large_batch(gpu, oracle_mod, tiny_geometry):
     assert stats['launches'] == ostats['launches'] and stats['photon_steps'] == ostats['photon_steps']
 
 
+def test_axis_plane_photons_stay_out_of_the_fast_walk_step_after_step(gpu, oracle_mod):
+    """A mirror box in vacuum: photons that start inside a coordinate plane (one direction component exactly 0, so
+    1/d is infinite: not a ray for the fast walk) are reflected inside that plane at every step.  At every step,
+    then, their ray record -- written by k_load_working for the first step, by k_physics for the later ones -- says
+    "not to be cast", and k_raycast_quad has to settle the slot (hit entry + retry list) when it meets it.
+    20 000 photons keep every step a per-step launch.  (Exactly axis-parallel photons would not do: the reference's
+    specular reflection at normal incidence divides 0 by 0, photon.h:620-624, and they end as NaN aborts.)"""
+    from chroma_amd.geometry import Surface, vacuum
+    mirror = Surface('mirror')
+    mirror.set('reflect_specular', 1.0)
+    geometry = make_box_geometry(200.0, material=vacuum, surface=mirror)
+    ph = bomb(20000, 5)
+    planes = np.array([[1, 1, 0], [0, 1, -1], [1, 0, 1], [-1, 2, 0]], dtype=float)
+    ph.dir[:8000] = np.tile(planes / np.linalg.norm(planes, axis=1)[:, None], (2000, 1))
+    ph.pos[:8000] = np.random.RandomState(1).uniform(-90, 90, (8000, 3))
+    gg, gp, got, want, counters, stats, ostats = run_both(gpu, oracle_mod, geometry, ph, max_steps=12)
+    assert_bit_exact(got, want, 'mirror box')
+    assert np.array_equal(gp.rng_counters.get(), counters)
+    assert stats['launches'] == ostats['launches'] == 12 and stats['photon_steps'] == ostats['photon_steps']
+    terminal = event.NO_HIT | event.BULK_ABSORB | event.SURFACE_DETECT | event.SURFACE_ABSORB | event.NAN_ABORT
+    alive = (got.flags[:8000] & terminal) == 0
+    assert alive.mean() > 0.95 and (got.flags[:8000][alive] & event.REFLECT_SPECULAR).all()
+    assert (np.abs(got.dir[:8000][alive]).min(axis=1) == 0).mean() > 0.99  # still inside their plane after 12 reflections
+
+
 @pytest.mark.parametrize('tail', ['split', 'fused'])
 def test_tail_modes_give_the_same_photons(gpu, oracle_mod, tiny_geometry, tail):
     """chroma_set_tail: per-step launch sets to the end, and the reference's own launch shape (the
