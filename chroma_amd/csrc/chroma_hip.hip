@@ -919,10 +919,7 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #ifndef QUAD_STACK
 #define QUAD_STACK COOP_STACK    // (node, distance) entries per ray in LDS
 #endif
-#ifndef QUAD_SIGNED_SLABS
-#define QUAD_SIGNED_SLABS 1  // near/far faces by the sign of the direction (box_interval_signed); origin and direction of a ray then
-#endif                       // live in LDS between its triangle rounds (the three shift registers have to come from somewhere)
-#define QUAD_OD_WORDS (QUAD_SIGNED_SLABS ? 6 : 0)
+#define QUAD_OD_WORDS 6       // origin and direction of a ray wait in LDS between its triangle rounds
 #define QUAD_STRIDE (2 * QUAD_STACK + QUAD_PENDING + QUAD_OD_WORDS + 1)     // words per ray, odd: staggers the banks
 #ifndef QUAD_REFILL_MIN
 #define QUAD_REFILL_MIN 4    // refill once this many of the 16 rays are done
@@ -930,26 +927,11 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #ifndef QUAD_WAVES_PER_EU
 #define QUAD_WAVES_PER_EU 7
 #endif
-#ifndef QUAD_UNIFORM_SPILL
-#define QUAD_UNIFORM_SPILL 1   // the spill paths of push and pop behind one wave-uniform test each
-#endif
 #ifndef QUAD_TIMING
 #define QUAD_TIMING 0        // diagnostic build: s_memtime stamps around the phases of a wave, printed by a few waves
 #endif
-#ifndef QUAD_SETPRIO
-#define QUAD_SETPRIO 1       // s_setprio around the node fetch (-0.6 %)
-#endif
 #ifndef QUAD_FLUSH
 #define QUAD_FLUSH 8         // run the triangle tests once a ray has this many postponed (a visit adds up to 8)
-#endif
-#ifndef QUAD_TRIGGER_LANES
-#define QUAD_TRIGGER_LANES 0 // (experiment) also run a round once this many lanes of the wave would have a triangle to test; 0 = off
-#endif
-#ifndef QUAD_POP_SELECT
-#define QUAD_POP_SELECT 1
-#endif
-#ifndef QUAD_LEAF_SELECT
-#define QUAD_LEAF_SELECT 1
 #endif
 #ifndef QUAD_KEEP
 #define QUAD_KEEP 7          // a triangle phase runs rounds until no ray with node work left holds more than this many (7: one round unless a ray holds 12+; -5 % against 0)
@@ -1040,16 +1022,10 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     // per-ray state, identical in the 4 lanes of a quad
     bool has_ray = false, active = false;
     int slot = 0;
-#if QUAD_SIGNED_SLABS
     float *ray_od = (float *)(stack_n + 2 * QUAD_STACK + QUAD_PENDING);      // origin, direction of this quad's ray
-#else
-    v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
-#endif
     float rax = 0.f, ray_ = 0.f, raz = 0.f; // RayFast::a (three scalars: as a struct it ended up in LDS), and {blo, bhi} per axis
     f32x2 rbx = {0.f, 0.f}, rby = {0.f, 0.f}, rbz = {0.f, 0.f};
-#if QUAD_SIGNED_SLABS
     uint32_t rsx = 0, rsy = 0, rsz = 0;     // 16 for an axis the ray runs down (box_interval_signed)
-#endif
     uint32_t last_hit_w = WIDE_NONE;        // the leaf word of the photon's last hit (never entered)
     int triangle_index = -1;
     uint32_t best_rank = 0;
@@ -1092,23 +1068,12 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 const float4 r0 = r[0], r1 = r[1];
                 if (__float_as_int(r1.w) == 0) {                 // (other slots were settled by k_ray_setup)
                     const float4 r2 = r[2], r3 = r[3];
-#if QUAD_SIGNED_SLABS
                     if (j == 0) { ray_od[0] = r0.x; ray_od[1] = r0.y; ray_od[2] = r0.z; ray_od[3] = r1.x; ray_od[4] = r1.y; ray_od[5] = r1.z; }
-#else
-                    origin = mk3(r0.x, r0.y, r0.z);
-                    direction = mk3(r1.x, r1.y, r1.z);
-#endif
                     { const int lh = __float_as_int(r0.w); last_hit_w = lh >= 0 ? (0x80000000u | (uint32_t)lh) : WIDE_NONE; }
                     rax = r2.x; ray_ = r2.y; raz = r2.z;
-#if QUAD_SIGNED_SLABS
                     { const float mx = cm_fabsf(rax), my = cm_fabsf(ray_), mz = cm_fabsf(raz);
                       rbx = (f32x2){r3.x - mx, r3.x + mx}; rby = (f32x2){r3.y - my, r3.y + my}; rbz = (f32x2){r3.z - mz, r3.z + mz}; }
                     rsx = rax < 0.f ? 16u : 0u; rsy = ray_ < 0.f ? 16u : 0u; rsz = raz < 0.f ? 16u : 0u;
-#else
-                    rbx = (f32x2){r3.x - rax, r3.x + rax};
-                    rby = (f32x2){r3.y - ray_, r3.y + ray_};
-                    rbz = (f32x2){r3.z - raz, r3.z + raz};
-#endif
                     triangle_index = -1;
                     prune_t = cm_inff();
                     sp = 0;
@@ -1141,12 +1106,8 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #if QUAD_TIMING
             TQ_STAMP(tq_a); tq_iters++; tq_active += (unsigned)__popcll(__ballot(active && j == 0));
 #endif
-#if QUAD_SETPRIO
             __builtin_amdgcn_s_setprio(3);       // a wave about to fetch its next node goes before waves that compute
-#endif
-#if QUAD_UNIFORM_SPILL
             if (!__any(sp > QUAD_STACK)) {
-#if QUAD_POP_SELECT
                 // (node, distance) read together, the entry kept or dropped by a select: no branch inside the loop
                 while (active && cur == WIDE_NONE) {
                     if (sp == 0) { active = false; break; }
@@ -1155,19 +1116,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     const float t = stack_t[sp];
                     cur = (t > prune_t) ? WIDE_NONE : n;
                 }
-#else
-                if (active && cur == WIDE_NONE) {
-                    while (sp > 0) {
-                        sp--;
-                        const uint32_t n = stack_n[sp];
-                        const float t = stack_t[sp];
-                        if (!(t > prune_t)) { cur = n; break; }
-                    }
-                    if (cur == WIDE_NONE) active = false;
-                }
-#endif
             } else
-#endif
             if (active && cur == WIDE_NONE) {
                 while (sp > 0) {
                     sp--;
@@ -1188,23 +1137,13 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 TQ_STAMP(tq_a); tq_wait += tq_a - tq_b;
 #endif
-#if QUAD_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
-#endif
                 if (COUNT && j == 0) cnt.nodes += 8;
                 float ta, tb, fa, fb;
-#if QUAD_SIGNED_SLABS
                 box_interval_signed(rax, ray_, raz, rsx, rsy, rsz, rbx, rby, rbz, ea, ta, fa);
                 box_interval_signed(rax, ray_, raz, rsx, rsy, rsz, rbx, rby, rbz, eb, tb, fb);
                 const bool pa = !(ta > fa) & !(ta > prune_t);        // (an empty entry fails the first test by itself)
                 const bool pb = !(tb > fb) & !(tb > prune_t);
-#else
-                box_interval_pk(rax, ray_, raz, rbx, rby, rbz, ea, ta, fa);
-                box_interval_pk(rax, ray_, raz, rbx, rby, rbz, eb, tb, fb);
-                // intersect_node (mesh.h:16-34) with prune_t = +inf until something is hit
-                const bool pa = (ea.w != WIDE_NONE) & !(ta > fa) & !(ta > prune_t);
-                const bool pb = (eb.w != WIDE_NONE) & !(tb > fb) & !(tb > prune_t);
-#endif
                 // (the photon's last hit is left out when its turn to be tested comes: one compare per triangle
                 //  round instead of two per visit)
                 const bool fa_leaf = (int)ea.w < 0, fb_leaf = (int)eb.w < 0;
@@ -1233,13 +1172,11 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     const uint32_t mo = mi & ~(1u << ne);
                     int pos = sp + __popc(mo & below2);
                     sp += __popc(mo);
-#if QUAD_UNIFORM_SPILL
                     if (!__any(sp > QUAD_STACK)) {
                         // every ray of the wave stays inside its LDS stack (almost always): two plain stores
                         if (qa) { stack_n[pos] = ea.w; stack_t[pos] = ta; pos++; }
                         if (qb) { stack_n[pos] = eb.w; stack_t[pos] = tb; }
                     } else
-#endif
                     {
                         if (qa) {
                             if (pos < QUAD_STACK) { stack_n[pos] = ea.w; stack_t[pos] = ta; }
@@ -1260,8 +1197,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #if QUAD_TIMING
             TQ_STAMP(tq_b); tq_node += tq_b - tq_a;       // (a_ = after the wait when the wave fetched, else the pop stamp)
 #endif
-        } while (!__any(npend >= QUAD_FLUSH) && (int)__popcll(__ballot(active) & 0x1111111111111111ull) > stop_at &&
-                 !(QUAD_TRIGGER_LANES && (int)__popcll(__ballot((int)j < npend)) >= QUAD_TRIGGER_LANES));
+        } while (!__any(npend >= QUAD_FLUSH) && (int)__popcll(__ballot(active) & 0x1111111111111111ull) > stop_at);
         __builtin_amdgcn_wave_barrier();      // (scheduling fence: the lanes of a quad exchange data through LDS)
 #if QUAD_TIMING
         TQ_STAMP(tq_a);
@@ -1272,7 +1208,6 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #if QUAD_TIMING
             tq_rounds++; tq_tests += (unsigned)__popcll(__ballot(npend > 0 && (int)j < min(npend, 4)));
 #endif
-#if QUAD_LEAF_SELECT
             {
                 // every lane runs the round; a ray without postponed triangles takes none and keeps its state
                 // through selects (the reductions are a few DPP operations: cheaper than the copies that
@@ -1286,9 +1221,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     if (COUNT) cnt.tris++;
                     const float4 *tp = g.tri + TRI_STRIDE * (size_t)tri;
                     float4 a = tp[0], b = tp[1], c = tp[2];
-#if QUAD_SIGNED_SLABS
                     const v3 origin = mk3(ray_od[0], ray_od[1], ray_od[2]), direction = mk3(ray_od[3], ray_od[4], ray_od[5]);
-#endif
                     hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
                     rank = __float_as_uint(c.w);
                 }
@@ -1306,41 +1239,6 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 phead = (phead + (uint32_t)take) & (QUAD_PENDING - 1u);
                 npend -= take;
             }
-#else
-            if (npend > 0) {
-                const int take = min(npend, 4);
-                bool hit = false;
-                float distance = 0.0f;
-                uint32_t tri = 0, rank = 0xFFFFFFFFu;
-                if ((int)j < take) tri = pending[(phead + j) & (QUAD_PENDING - 1u)];
-                if ((int)j < take && (0x80000000u | tri) != last_hit_w) {
-                    if (COUNT) cnt.tris++;
-                    const float4 *tp = g.tri + TRI_STRIDE * (size_t)tri;
-                    float4 a = tp[0], b = tp[1], c = tp[2];
-#if QUAD_SIGNED_SLABS
-                    const v3 origin = mk3(ray_od[0], ray_od[1], ray_od[2]), direction = mk3(ray_od[3], ray_od[4], ray_od[5]);
-#endif
-                    hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
-                    rank = __float_as_uint(c.w);
-                }
-                // distances are positive: their bit patterns order like the floats
-                const uint32_t dkey = hit ? __float_as_uint(distance) : 0x7F800000u;
-                const uint32_t dmin = quad_min_u32(dkey);
-                if (dmin != 0x7F800000u) {
-                    const float dm = __uint_as_float(dmin);
-                    const bool cand = hit && dkey == dmin;
-                    const uint32_t rm = quad_min_u32(cand ? rank : 0xFFFFFFFFu);
-                    const uint32_t wtri = quad_max_u32((cand && rank == rm) ? tri + 1u : 0u) - 1u;
-                    if (dm < prune_t || (dm == prune_t && rm < best_rank)) {
-                        triangle_index = (int)wtri;
-                        prune_t = dm;
-                        best_rank = rm;
-                    }
-                }
-                phead = (phead + (uint32_t)take) & (QUAD_PENDING - 1u);
-                npend -= take;
-            }
-#endif
         }
 
 
