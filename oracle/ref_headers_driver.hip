@@ -15,6 +15,7 @@
 #include "rotate.h"
 #include "interpolate.h"
 #include "geometry.h"
+#include "transform.cu"       // the reference's three point-transform kernels (chroma/cuda/transform.cu:9-49), by path, unmodified
 
 extern "C" __global__ void ref_k_interp_property(int n, const float *x, const float *fp, int wavelength_n,
                                                  float wavelength_start, float wavelength_step, float *out)
@@ -63,9 +64,27 @@ extern "C" __global__ void ref_k_rotate(int n, const float *in, float *out)
 // fn 1: interp_idx        x[n], tab_x[ntab]
 // fn 2: interp            x[n], tab_x[ntab], tab_f[ntab]
 // fn 3: rotate            x[7 n] -> out[5 n]
+// fn 4..6: the kernels of transform.cu on n points x[3 n] -> out[3 n]; tab_x = v[3] (translate), {phi, axis[3]} (rotate),
+//          {phi, axis[3], point[3]} (rotate_around_point)
 extern "C" int ref_headers_run(int fn, int n, const float *x, const float *tab_x, const float *tab_f, int ntab,
                                float start, float step, float *out)
 {
+    if (fn >= 4 && fn <= 6) {
+        if (!tab_x) return -1;
+        float3 *d_a = nullptr;
+        CK(hipMalloc(&d_a, (size_t)n * sizeof(float3)));
+        CK(hipMemcpy(d_a, x, (size_t)n * sizeof(float3), hipMemcpyHostToDevice));
+        const int block = 256, grid = (n + block - 1) / block;
+        if (fn == 4) hipLaunchKernelGGL(translate, dim3(grid), dim3(block), 0, 0, n, d_a, make_float3(tab_x[0], tab_x[1], tab_x[2]));
+        else if (fn == 5) hipLaunchKernelGGL(rotate, dim3(grid), dim3(block), 0, 0, n, d_a, tab_x[0], make_float3(tab_x[1], tab_x[2], tab_x[3]));
+        else hipLaunchKernelGGL(rotate_around_point, dim3(grid), dim3(block), 0, 0, n, d_a, tab_x[0], make_float3(tab_x[1], tab_x[2], tab_x[3]),
+                                make_float3(tab_x[4], tab_x[5], tab_x[6]));
+        CK(hipGetLastError());
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(out, d_a, (size_t)n * sizeof(float3), hipMemcpyDeviceToHost));
+        hipFree(d_a);
+        return 0;
+    }
     const size_t nin = (size_t)n * (fn == 3 ? 7 : 1), nout = (size_t)n * (fn == 3 ? 5 : 1);
     float *d_x = nullptr, *d_tx = nullptr, *d_tf = nullptr, *d_out = nullptr;
     CK(hipMalloc(&d_x, nin * 4));

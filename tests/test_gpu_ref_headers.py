@@ -118,3 +118,47 @@ def test_rotate(oracle_mod):
     # everywhere: within the float tolerance of the north star (|a| = 1)
     assert np.abs(orc[:, :3].astype(np.float64) - want[:, :3]).max() < 1e-5
     assert np.abs(orc[:, 3:].astype(np.float64) - want[:, 3:]).max() < 1e-6         # contract cos/sin vs the device library
+
+
+@needs_ref
+def test_point_transform_kernels():
+    """chroma_points_translate / _rotate / _rotate_around_point against the reference's own kernels
+    (chroma/cuda/transform.cu:9-49, compiled for gfx950 from where they lie): translate bit for bit; the two
+    rotations bit for bit wherever the contract's cos/sin of the angle equal the device library's (the test above
+    counts how often that is), and within the north star's float tolerance for the others."""
+    from chroma_amd import gpu, _lib
+    from chroma_amd.gpu.tools import to_gpu
+    ctx = gpu.get_context()
+    ref = ctypes.CDLL(REF_LIB)
+    rng = np.random.default_rng(11)
+    n = 50000
+    pts = rng.uniform(-2000, 2000, (n, 3)).astype(np.float32)
+    f3 = lambda v: (ctypes.c_float * 3)(*[float(c) for c in v])
+
+    def ref_run(fn, params):
+        out = np.empty_like(pts)
+        t = np.ascontiguousarray(params, np.float32)
+        rc = ref.ref_headers_run(fn, n, pts.ctypes.data_as(ctypes.c_void_p), t.ctypes.data_as(ctypes.c_void_p), None, len(t),
+                                 ctypes.c_float(0.0), ctypes.c_float(1.0), out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        return out
+
+    v = np.array([12.5, -3.25, 1e-3], np.float32)
+    d = to_gpu(pts.reshape(-1).copy(), ctx)
+    _lib.check(ctx._lib.chroma_points_translate(ctx.handle, n, d.ptr, f3(v)))
+    assert np.array_equal(bits(d.get().reshape(n, 3)), bits(ref_run(4, v)))
+
+    axis = np.array([0.3, -0.5, 0.81], np.float32); axis /= np.linalg.norm(axis)
+    point = np.array([100.0, 50.0, -25.0], np.float32)
+    exact = 0
+    for phi in (0.0, 0.5, np.pi / 2, -2.0, 3.0, 1e-4):
+        d = to_gpu(pts.reshape(-1).copy(), ctx)
+        _lib.check(ctx._lib.chroma_points_rotate(ctx.handle, n, d.ptr, float(phi), f3(axis)))
+        got, want = d.get().reshape(n, 3), ref_run(5, np.concatenate([[phi], axis]))
+        assert np.abs(got.astype(np.float64) - want).max() < 1e-5 * 4000
+        d = to_gpu(pts.reshape(-1).copy(), ctx)
+        _lib.check(ctx._lib.chroma_points_rotate_around_point(ctx.handle, n, d.ptr, float(phi), f3(axis), f3(point)))
+        got2, want2 = d.get().reshape(n, 3), ref_run(6, np.concatenate([[phi], axis, point]))
+        assert np.abs(got2.astype(np.float64) - want2).max() < 1e-5 * 4000
+        exact += int(np.array_equal(bits(got), bits(want)) and np.array_equal(bits(got2), bits(want2)))
+    assert exact >= 2, 'bit-exact for %d of 6 angles' % exact
