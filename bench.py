@@ -111,8 +111,22 @@ def main():
     if world > 1:
         if torch is None:
             raise SystemExit('multi-GPU runs need torch.distributed')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        # (CHROMA_BENCH_BACKEND=gloo is a REHEARSAL of the multi-rank flow on a box with fewer GPUs than ranks: ranks
+        #  share devices, rendezvous and reductions go through gloo on host tensors, and the library's RCCL communicator
+        #  -- which refuses two ranks on one device -- gives way to the torch.distributed fallback below.  Its number
+        #  means nothing.)
+        backend = os.environ.get('CHROMA_BENCH_BACKEND', 'nccl')
+        ndev = max(1, torch.cuda.device_count())
+        device_index = local_rank % ndev
+        torch.cuda.set_device(device_index)
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', device_index))
+            reduce_device = torch.device('cuda', device_index)
+        else:
+            dist.init_process_group(backend=backend)
+            reduce_device = torch.device('cpu')
+    else:
+        device_index = local_rank
 
     import ctypes
     import numpy as np
@@ -158,20 +172,21 @@ def main():
         args.config, d.ntriangles, d.nnodes, d.nwide, d.nchannels,
         'built + wide tree' if (world == 1 or local_rank == 0) else 'mapped from /dev/shm', t_build))
 
-    ctx = gpu.create_cuda_context(local_rank)
+    ctx = gpu.create_cuda_context(device_index)
     t0 = time.time()
     gg = gpu.GPUDetector.from_packed(packed)
     lib_comm = True
     if world > 1:
         # the library's own RCCL communicator (reductions in place on the device arrays).  Should it not come up on
         # some rank, ALL ranks agree to reduce through torch.distributed instead (same RCCL, staged through tensors)
-        try:
-            init_comm(ctx)
-            ok = 1
-        except Exception as exc:        # pragma: no cover
-            log('rank %d: library communicator unavailable (%s)' % (rank, exc))
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device('cuda', local_rank))
+        ok = 0
+        if backend == 'nccl':
+            try:
+                init_comm(ctx)
+                ok = 1
+            except Exception as exc:        # pragma: no cover
+                log('rank %d: library communicator unavailable (%s)' % (rank, exc))
+        flag = torch.tensor([ok], dtype=torch.int32, device=reduce_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         lib_comm = bool(int(flag.item()))
         if not lib_comm:
@@ -255,7 +270,7 @@ def main():
             c, e = counts.get(), earliest.get()
         else:                           # pragma: no cover
             from chroma_amd.dist import allreduce_channel_hits
-            c, e = allreduce_channel_hits(counts.get(), earliest.get(), device=torch.device('cuda', local_rank))
+            c, e = allreduce_channel_hits(counts.get(), earliest.get(), device=reduce_device)
         for k, v in st.as_dict().items():
             stats[k] = stats.get(k, 0) + v
         stats['hits'] = stats.get('hits', 0) + int(nhits.value)
@@ -315,7 +330,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=torch.device('cuda', local_rank))
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -411,7 +426,8 @@ def main():
                        'bvh_nodes': int(d.nnodes), 'channels': int(d.nchannels),
                        'photons_per_gpu_per_step': nphotons, 'max_steps': args.max_steps,
                        'wavelength_nm': [wl_lo, wl_hi] if wl_hi > wl_lo else wl_lo,
-                       'engine_seed': ENGINE_SEED, 'parallelism': 'photon shards x%d, geometry replicated, per-channel arrays all-reduced (RCCL)' % world,
+                       'engine_seed': ENGINE_SEED, 'parallelism': 'photon shards x%d, geometry replicated, per-channel arrays all-reduced (%s)' % (
+                           world, 'RCCL inside the library' if lib_comm else ('torch.distributed, %s' % (backend if world > 1 else '-'))),
                        'step': 'propagate(max_steps) + channel hit arrays + flat-hit count and compaction' + (' + all-reduce' if world > 1 else ''),
                        'inputs': 'resident in HBM' if resident else 'bomb regenerated on the device inside the timed region (memory)',
                        'target_photons_per_s_per_gpu': 2.5e6, 'vs_target': value / world / 2.5e6,
