@@ -1,0 +1,50 @@
+"""The one JSON line `bench.py` prints is a contract with the driver (metric, value, unit, n_gpus, steps, warmup,
+ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config.workload + the `roofline` and `cpu_baseline`
+objects): run it as the driver does -- a child process -- on the smallest configuration and check the line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(*extra):
+    env = dict(os.environ)
+    env.pop('CHROMA_BENCH_GEOMETRY_CACHE', None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', 'tiny', '--steps', '2', '--warmup', '1'] + list(extra),
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, 'exactly one line on stdout: %r' % lines
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_line_carries_the_contract():
+    j = _run()
+    assert j['metric'].startswith('photons/sec') and j['unit'] == 'photons/s' and j['higher_is_better'] is True
+    assert j['n_gpus'] == 1 and j['steps'] == 2 and j['warmup'] == 1 and j['scaling'] == 'weak'
+    assert j['vs_baseline'] is None and j['dtype'] == 'f32' and j['data'] == 'synthetic'
+    assert 'workload' in j['config'] and 'model' not in j['config']
+    assert j['value'] > 1e7 and abs(j['value'] * j['ms_per_step'] * 1e-3 / j['config']['photons_per_gpu_per_step'] - 1.0) < 1e-6
+    r = j['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.0 < r['frac'] < 1.0
+    assert 'traffic' in r and 'traffic_source' in r and r['launches'] > 0 and r['avg_launch_ms'] > 0
+    # algorithmic bytes per launch over the measured launch time IS `achieved`
+    assert abs(r['algorithmic_bytes_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e9 - r['achieved']) < 1e-6 * r['achieved']
+    c = j['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['unit'] == 'photons/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']
+
+
+@pytest.mark.timeout(900)
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', 'tiny', '--gpus', '1', '--steps', '1', '--warmup', '0'],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b'WORLD_SIZE' in p.stderr + p.stdout
