@@ -1843,7 +1843,7 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
 #define PHYS_WAVES_PER_EU 4
 #endif
 #ifndef PHYS_SORT
-#define PHYS_SORT 1          // deal the slots of a block to its threads by the kind of surface hit
+#define PHYS_SORT 1          // all-models build: deal the slots of a block to its threads by the kind of surface hit
 #endif
 #define PHYS_CLASSES 8
 #ifndef PHYS_PLAIN_WAVES_PER_EU
@@ -1862,14 +1862,15 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
     // taken as they are.  A photon that survives the step is appended to the next working set; one that
     // ends here is written to the caller's arrays (the only time they are touched).
     __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
-#if PHYS_SORT
     // The 512 slots of a round are dealt to the threads BY THE SURFACE THEY HIT (the material code of the winning
-    // triangle's record): what a photon does at a black wall, at PMT glass, at the photocathode or at a mirror are
-    // different, long branches (Fresnel alone is a third of the kernel), and a wave that holds all kinds executes
-    // them all.  Sorted, most waves hold one kind and skip the rest.  Only slot numbers move (through LDS).
-    __shared__ uint32_t s_class_count[PHYS_BLOCK / WAVE][PHYS_CLASSES];
-    __shared__ int32_t s_perm[PHYS_BLOCK];
-#endif
+    // triangle's record): what a photon does at a black wall, at PMT glass, at the photocathode, at a mirror, a thin
+    // film or a wavelength shifter are different, long branches, and a wave that holds all kinds executes them all.
+    // Sorted, most waves hold one kind and skip the rest.  Only slot numbers move (through LDS).  In the ALL-MODELS
+    // build only (-8 % at C5): with plain optics the step's divergence is in the bulk, not at the surface, and the four
+    // barriers and the extra gather of the sort cost 2 ms per C3 step (profiles/r02/ab_physics_sort.txt).
+    constexpr bool SORT = FULL && (PHYS_SORT != 0);
+    __shared__ uint32_t s_class_count[SORT ? PHYS_BLOCK / WAVE : 1][PHYS_CLASSES];
+    __shared__ int32_t s_perm[SORT ? PHYS_BLOCK : 1];
     const int nthreads = fixup ? (int)st->retry : (int)st->n, renorm = (int)st->renorm, renorm_next = st->in_tail ? 0 : 1;
     unsigned long long nsteps = 0;
     // the grid is sized for an upper bound of the photon count: blocks stride over the slots
@@ -1880,9 +1881,8 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
     Photon p;
     uint32_t counter = 0;
     int last_hit_record = -1;
-#if PHYS_SORT
     int sorted_slot = (id < nthreads) ? id : -1;
-    if (!fixup) {
+    if (SORT && !fixup) {
         // class of this thread's own slot: 0 = nothing to do here (no slot, miss, NaN, retry), else 1 + surface kind
         uint32_t cls = 0;
         if (id < nthreads) {
@@ -1919,10 +1919,6 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
     }
     if (sorted_slot >= 0) {
         const int slot = fixup ? (int)retry_list[sorted_slot] : sorted_slot;
-#else
-    if (id < nthreads) {
-        const int slot = fixup ? (int)retry_list[id] : id;
-#endif
         int tri = hit_triangle[slot];
         const float hit_dist = hit_distance[slot];
         float4 w0, w1, w2, w3;
