@@ -1,0 +1,34 @@
+"""The path with HOST photons on both ends (what chroma.sim.Simulation does per event batch): GPUPhotons(host arrays) ->
+propagate -> get_flat_hits back to the host.  bench.py's `value` has its inputs resident in HBM; this is the
+PCIe-inclusive figure DESIGN.md section 7 quotes next to it.  usage: pcie_rate.py [c3|detector|lite|tiny] [photons]  (GPU box)"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from chroma_amd import demo, gpu
+from chroma_amd.event import Photons
+from chroma_amd.loader import create_geometry_from_obj
+from chroma_amd.gpu.geometry import pack_geometry
+
+config = sys.argv[1] if len(sys.argv) > 1 else 'c3'
+n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 50_000_000
+geo = create_geometry_from_obj({'tiny': demo.tiny, 'lite': demo.detector_lite, 'detector': demo.detector, 'c3': demo.detector29k}[config]())
+ctx = gpu.create_cuda_context(0)
+gg = gpu.GPUDetector(geo, packed=pack_geometry(geo))
+rng = np.random.default_rng(1)
+d = rng.standard_normal((n, 3), dtype=np.float32); d /= np.linalg.norm(d, axis=1)[:, None]
+pol = np.cross(d, np.roll(d, 1, axis=1)).astype(np.float32); pol /= np.linalg.norm(pol, axis=1)[:, None]
+host = Photons(np.zeros((n, 3), np.float32), d, pol, np.full(n, 400.0, np.float32))
+rs = gpu.get_rng_states(64, seed=7)
+for rep in range(3):
+    t0 = time.perf_counter()
+    gp = gpu.GPUPhotons(host)
+    ctx.synchronize(); t1 = time.perf_counter()
+    gp.propagate(gg, rs, max_steps=100)
+    ctx.synchronize(); t2 = time.perf_counter()
+    hits = gp.get_flat_hits(gg)
+    t3 = time.perf_counter()
+    print('%s, %d host photons: upload %.3f s (%.1f GB/s), propagate %.3f s, flat hits to host (%d) %.3f s -> %.3g photons/s '
+          'end to end, %.3g with resident inputs' % (config, n, t1 - t0, n * 64e-9 / (t1 - t0), t2 - t1, len(hits), t3 - t2,
+                                                     n / (t3 - t0), n / (t3 - t1)), flush=True)
+    del gp, hits
