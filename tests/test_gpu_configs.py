@@ -177,6 +177,15 @@ def test_c3_full_batch_properties(gpu, c3):
     walks_agree(gpu, c3, 10_000_000, id_base=1 << 32)
 
 
+def test_c4_one_shard_of_the_billion_photon_job(gpu, c3):
+    """BASELINE.json configs[3] (C4) is 1e9 photons over 8 GPUs: 1.25e8 per GPU, photon ids of rank r starting at
+    r * 1.25e8.  The eight-GPU job is the driver's to run; here ONE GPU runs the last rank's shard at its full size
+    (ids 8.75e8 ... 1e9: the capacity of every per-photon buffer, id arithmetic beyond 2^29) through the same
+    property checks as the C3 batch."""
+    stats, nhits = batch_properties(gpu, c3, 125_000_000, id_base=7 * 125_000_000)
+    assert 0.03 < nhits / 1.25e8 < 0.15
+
+
 # ---- C2: demo.detector(), 10 055 PMTs, 59 M triangles (configs[1]) -----------------------------------------
 def test_c2_one_million_photons_match_the_oracle(gpu, oracle_mod, c2):
     gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c2, 1_000_000, 'C2 demo.detector(), 1e6 photons')
