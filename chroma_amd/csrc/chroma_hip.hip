@@ -925,8 +925,8 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
 #define QUAD_REFILL_MIN 4    // refill once this many of the 16 rays are done
 #endif
 #ifndef QUAD_WAVES_PER_EU
-#define QUAD_WAVES_PER_EU 7
-#endif
+#define QUAD_WAVES_PER_EU 8  // 63 VGPRs; the one value that does not fit (the base of the global spill area) is reloaded from
+#endif                       // scratch in the rare deep-stack push only.  -4 % against 7 (68 VGPRs), profiles/r02/ab_quad_8waves.txt
 #ifndef QUAD_TIMING
 #define QUAD_TIMING 0        // diagnostic build: s_memtime stamps around the phases of a wave, printed by a few waves
 #endif

@@ -26,12 +26,15 @@ def isa_table():
 
 @pytest.mark.timeout(1000)
 def test_ray_cast_kernels_hold_their_state_in_registers(isa_table):
-    for name in ('k_raycast_quad<false>', 'k_raycast_coop<false>'):
-        k = isa_table[name]
-        assert k['scratch'] == 0 and k['waves'] == 7 and k['vgpr'] <= 72, (name, k)
-    # the counting build (untimed: one pass per bench run, and the parity tests) may keep a few words in scratch
+    k = isa_table['k_raycast_coop<false>']
+    assert k['scratch'] == 0 and k['waves'] == 7 and k['vgpr'] <= 72, k
+    # the product walk runs at the full 8 waves per SIMD: 64 VGPRs at most, and nothing in scratch but the base pointer
+    # of the global spill area (12 bytes, reloaded in the deep-stack push only: see the kernel's QUAD_WAVES_PER_EU)
+    k = isa_table['k_raycast_quad<false>']
+    assert k['scratch'] <= 16 and k['waves'] == 8 and k['vgpr'] <= 64, k
+    # the counting build (untimed: one pass per bench run, and the parity tests) may keep a few more words there
     k = isa_table['k_raycast_quad<true>']
-    assert k['scratch'] <= 32 and k['waves'] == 7, k
+    assert k['scratch'] <= 48 and k['waves'] == 8, k
     # exactly the 16 per-ray areas (24 stack entries of two words, a ring of 16 postponed triangles, origin and
     # direction, one word of padding): a struct the compiler cannot keep in registers is "promoted" to LDS silently
     # (768 bytes per wave until RayFast::a became three scalars)
