@@ -439,7 +439,7 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': RAYCAST_KERNEL, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'hbm_measured_GBps': measured, 'hbm_measured_frac': (measured / HBM_PEAK_GBS) if measured else None,
-                         'limiter': 'VALU issue (PMC: SQ_ACTIVE_INST_VALU x 4 = 96 % of the SIMD cycles of the launches), not bandwidth',
+                         'limiter': 'VALU issue (PMC, profiles/r02/pmc_quad_final.txt: SQ_ACTIVE_INST_VALU x 4 = 98 % of the SIMD cycles of the launches), not bandwidth',
                          'algorithmic_bytes_per_launch': ray_bytes_total / ray_launches,
                          'algorithmic_bytes_per_photon_step': ray_bytes_per_step,
                          'launches': int(stats['raycast_launches']), 'avg_launch_ms': avg_launch_ms,
