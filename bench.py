@@ -58,6 +58,23 @@ def kernel_source_hash():
     return h.hexdigest()[:12]
 
 
+def geometry_source_hash():
+    """Identifies what a cached PackedGeometry was built from (CHROMA_BENCH_GEOMETRY_CACHE): the tree topology switch
+    and the sources of the host builders and of the demo geometries."""
+    h = hashlib.sha256(os.environ.get('CHROMA_TREE', 'sah').encode())
+    names = [os.path.join('chroma_amd', 'csrc', n) for n in ('wide_build.cpp', 'wide_build.h', 'bvh_build.cpp', 'mesh_utils.cpp', 'bvh_device.hip')]
+    for sub in ('demo', 'bvh'):
+        names += sorted(os.path.join('chroma_amd', sub, n) for n in os.listdir(os.path.join(ROOT, 'chroma_amd', sub)) if n.endswith('.py'))
+    names += [os.path.join('chroma_amd', n) for n in ('geometry.py', 'detector.py', 'make.py', 'pmt.py', 'transform.py', 'loader.py', os.path.join('gpu', 'geometry.py'))]
+    for name in names:
+        try:
+            with open(os.path.join(ROOT, name), 'rb') as f:
+                h.update(name.encode() + f.read())
+        except OSError:
+            pass
+    return h.hexdigest()[:12]
+
+
 def effective_cores():
     """Host threads this process may really use: the affinity mask, capped by the cgroup's CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -119,11 +136,14 @@ def main():
         ndev = max(1, torch.cuda.device_count())
         device_index = local_rank % ndev
         torch.cuda.set_device(device_index)
+        # (a timeout well under the driver's limit on the rendezvous and on every start-up collective: a rank that
+        #  never arrives fails the others instead of leaving them waiting)
+        from chroma_amd.dist import init_process_group
         if backend == 'nccl':
-            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', device_index))
+            init_process_group('nccl', device_id=torch.device('cuda', device_index))
             reduce_device = torch.device('cuda', device_index)
         else:
-            dist.init_process_group(backend=backend)
+            init_process_group(backend)
             reduce_device = torch.device('cpu')
     else:
         device_index = local_rank
@@ -135,7 +155,7 @@ def main():
     from chroma_amd.gpu.geometry import pack_geometry
     from chroma_amd.gpu.photon import _structure, _alloc_fields, GPUPhotonsSlice
     from chroma_amd.gpu.tools import GPUArray, zeros, empty
-    from chroma_amd.dist import init_comm, publish_packed_geometry, remove_published
+    from chroma_amd.dist import init_comm, publish_packed_geometry, remove_published, all_agree
 
     builder, nphotons, desc = CONFIGS[args.config]
     if args.photons:
@@ -151,16 +171,20 @@ def main():
         geo = create_geometry_from_obj(getattr(demo, builder)())
         return pack_geometry(geo).attach_wide_tree()
     shm_path = None
+    geometry_cached = False
     if world > 1:
         packed, shm_path = publish_packed_geometry(build_packed, 'bench_' + args.config, local_rank, dist.barrier)
         # the uploads (validation, staging) run in every rank at once: share the cores from here on
         os.environ.setdefault('CHROMA_HOST_THREADS', str(max(4, effective_cores() // max(1, local_world))))
     elif os.environ.get('CHROMA_BENCH_GEOMETRY_CACHE'):
         # repeated runs on one box (A/B series, counter passes): the packed geometry is kept between them
+        # (keyed by everything the saved arrays depend on: the tree topology switch, the builders' sources, the demo
+        #  geometry's sources -- a change to any of them builds afresh instead of silently reusing the old tree)
         from chroma_amd.gpu.geometry import PackedGeometry
-        cache = os.path.join(os.environ['CHROMA_BENCH_GEOMETRY_CACHE'], args.config)
+        cache = os.path.join(os.environ['CHROMA_BENCH_GEOMETRY_CACHE'], '%s_%s' % (args.config, geometry_source_hash()))
         if os.path.exists(os.path.join(cache, 'desc.json')):
             packed = PackedGeometry.load(cache, mmap=True)
+            geometry_cached = True
         else:
             packed = build_packed()
             packed.save(cache)
@@ -170,7 +194,8 @@ def main():
     d = packed.desc
     log('%s: %d triangles, %d nodes, %d wide nodes, %d channels; %s in %.1f s' % (
         args.config, d.ntriangles, d.nnodes, d.nwide, d.nchannels,
-        'built + wide tree' if (world == 1 or local_rank == 0) else 'mapped from /dev/shm', t_build))
+        'loaded from the geometry cache' if geometry_cached else
+        'built + wide tree' if (world == 1 or local_rank == 0) else 'mapped from %s' % shm_path, t_build))
 
     ctx = gpu.create_cuda_context(device_index)
     t0 = time.time()
@@ -179,16 +204,15 @@ def main():
     if world > 1:
         # the library's own RCCL communicator (reductions in place on the device arrays).  Should it not come up on
         # some rank, ALL ranks agree to reduce through torch.distributed instead (same RCCL, staged through tensors)
-        ok = 0
+        # (init_comm fails on ALL ranks together or on none: dist.StartupError)
+        lib_comm = False
         if backend == 'nccl':
             try:
                 init_comm(ctx)
-                ok = 1
+                lib_comm = True
             except Exception as exc:        # pragma: no cover
-                log('rank %d: library communicator unavailable (%s)' % (rank, exc))
-        flag = torch.tensor([ok], dtype=torch.int32, device=reduce_device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        lib_comm = bool(int(flag.item()))
+                print('[bench] rank %d: library communicator unavailable (%s)' % (rank, exc), file=sys.stderr, flush=True)
+        lib_comm = all_agree(lib_comm)
         if not lib_comm:
             ctx._lib.chroma_comm_destroy(ctx.handle)
             log('reducing the per-channel arrays through torch.distributed')
@@ -432,7 +456,10 @@ def main():
                        'inputs': 'resident in HBM' if resident else 'bomb regenerated on the device inside the timed region (memory)',
                        'target_photons_per_s_per_gpu': 2.5e6, 'vs_target': value / world / 2.5e6,
                        'steps_per_photon': steps_pp, 'nodes_per_step': nodes_ps, 'triangle_tests_per_step': tris_ps,
-                       'geometry_build_s': t_build, 'geometry_upload_s': t_upload},
+                       'geometry_build_s': t_build, 'geometry_cached': geometry_cached, 'geometry_upload_s': t_upload,
+                       'reduction': ('none: one GPU' if world == 1 and not os.environ.get('CHROMA_BENCH_COMM') else
+                                     'library RCCL (chroma_allreduce_hits, in place on the device arrays)' if lib_comm else
+                                     'torch.distributed fallback (%s), staged through host tensors' % backend)},
             # achieved/frac: ALGORITHMIC bytes over the HIP-event time of the ray-cast launches (cache hits included, so
             # this is effective bandwidth); traffic: fabric-side bytes per launch from PMC counters of this very build,
             # hbm_measured_*: that traffic over the same launch time.  The kernel is latency-bound.
@@ -456,4 +483,14 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # a rank that fails must END (non-zero), at once: the launcher then stops the others.  No clean-up of process
+        # groups here -- destroy_process_group on a broken group is itself a place to hang
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

@@ -4023,11 +4023,15 @@ int chroma_allreduce_hits(chroma_ctx *ctx, uint32_t *d_hit_count, uint32_t *d_ea
 {
     if (!ctx || !d_hit_count) return set_error(CHROMA_ERR_INVALID, "bad argument");
     if (!ctx->comm || nchannels == 0) return CHROMA_OK;
+    // (the first error is kept and the group is ALWAYS closed: an early return between GroupStart and GroupEnd would
+    //  leave the group open for every later RCCL call of the process -- torch's included, the library is shared)
     RCCL_TRY(g_rccl.GroupStart());
-    RCCL_TRY(g_rccl.AllReduce(d_hit_count, d_hit_count, nchannels, ncclUint32, ncclSum, ctx->comm, ctx->stream));
-    if (d_earliest_time_bits)
-        RCCL_TRY(g_rccl.AllReduce(d_earliest_time_bits, d_earliest_time_bits, nchannels, ncclUint32, ncclMin, ctx->comm, ctx->stream));
-    RCCL_TRY(g_rccl.GroupEnd());
+    ncclResult_t first = g_rccl.AllReduce(d_hit_count, d_hit_count, nchannels, ncclUint32, ncclSum, ctx->comm, ctx->stream);
+    if (first == ncclSuccess && d_earliest_time_bits)
+        first = g_rccl.AllReduce(d_earliest_time_bits, d_earliest_time_bits, nchannels, ncclUint32, ncclMin, ctx->comm, ctx->stream);
+    const ncclResult_t end = g_rccl.GroupEnd();
+    if (first == ncclSuccess) first = end;
+    if (first != ncclSuccess) return set_error(CHROMA_ERR_INVALID, "chroma_allreduce_hits: %s", g_rccl.GetErrorString(first));
     return CHROMA_OK;
 }
 
@@ -4049,10 +4053,14 @@ int chroma_allreduce_daq(chroma_ctx *ctx, uint32_t *d_earliest_time_int, uint32_
         ctx->gather_capacity = need;
     }
     RCCL_TRY(g_rccl.GroupStart());
-    RCCL_TRY(g_rccl.AllReduce(d_earliest_time_int, d_earliest_time_int, nchannels, ncclUint32, ncclMin, ctx->comm, ctx->stream));
-    RCCL_TRY(g_rccl.AllReduce(d_channel_q_int, d_channel_q_int, nchannels, ncclUint32, ncclSum, ctx->comm, ctx->stream));
-    RCCL_TRY(g_rccl.AllGather(d_channel_histories, ctx->gather_buf, nchannels, ncclUint32, ctx->comm, ctx->stream));
-    RCCL_TRY(g_rccl.GroupEnd());
+    ncclResult_t first = g_rccl.AllReduce(d_earliest_time_int, d_earliest_time_int, nchannels, ncclUint32, ncclMin, ctx->comm, ctx->stream);
+    if (first == ncclSuccess)
+        first = g_rccl.AllReduce(d_channel_q_int, d_channel_q_int, nchannels, ncclUint32, ncclSum, ctx->comm, ctx->stream);
+    if (first == ncclSuccess)
+        first = g_rccl.AllGather(d_channel_histories, ctx->gather_buf, nchannels, ncclUint32, ctx->comm, ctx->stream);
+    const ncclResult_t end = g_rccl.GroupEnd();          // (always: see chroma_allreduce_hits)
+    if (first == ncclSuccess) first = end;
+    if (first != ncclSuccess) return set_error(CHROMA_ERR_INVALID, "chroma_allreduce_daq: %s", g_rccl.GetErrorString(first));
     hipLaunchKernelGGL(k_or_gathered, dim3((nchannels + 255) / 256), dim3(256), 0, ctx->stream, d_channel_histories,
                        ctx->gather_buf, nchannels, ctx->comm_nranks);
     HIP_TRY(hipGetLastError());

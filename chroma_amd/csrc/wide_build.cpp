@@ -777,8 +777,15 @@ int validate_wide_tree(const uint32_t *wnodes, size_t nwide, const uint32_t *tri
             const uint32_t *wn = wnodes + i * 32;
             for (int j = 0; j < (int)WIDE_K; j++) {
                 const uint32_t w = wn[4 * j + 3];
-                if (w == WIDE_EMPTY) continue;
-                const bool ok = (w & WIDE_LEAF) ? (size_t)(w & ~WIDE_LEAF) < nrecords : ((size_t)w < nwide && (size_t)w > i);
+                // k_raycast_quad does not look at the child word of an entry whose box fails the slab test, and relies on
+                // an EMPTY entry carrying the inverted box (lo = 0xFFFF, hi = 0 on every axis) to fail it: an empty word
+                // with a real box would be taken for leaf record 0x7FFFFFFF
+                if (w == WIDE_EMPTY) {
+                    if (wn[4 * j] != 0x0000FFFFu || wn[4 * j + 1] != 0x0000FFFFu || wn[4 * j + 2] != 0x0000FFFFu) { note(i); break; }
+                    continue;
+                }
+                bool ok = (w & WIDE_LEAF) ? (size_t)(w & ~WIDE_LEAF) < nrecords : ((size_t)w < nwide && (size_t)w > i);
+                for (int ax = 0; ax < 3; ax++) ok = ok && (wn[4 * j + ax] & 0xFFFFu) <= (wn[4 * j + ax] >> 16);
                 if (!ok) { note(i); break; }
             }
         }

@@ -42,8 +42,11 @@ def load_bvh(geometry, bvh_name="default", auto_build_bvh=True, read_bvh_cache=T
 def create_geometry_from_obj(obj, bvh_name="default", auto_build_bvh=True, read_bvh_cache=True,
                              update_bvh_cache=True, cache_dir=None, cuda_device=None):
     """Flatten a Geometry/Detector (or wrap a Solid/Mesh in one) and attach its BVH
-    (chroma/loader.py:46-88)."""
+    (chroma/loader.py:46-88).  A callable is called first (chroma/loader.py:166: ``if callable(obj): obj = obj()``),
+    so a module-level Geometry / Solid / Mesh works as well as a function that returns one."""
     from chroma_amd.geometry import Geometry, Solid, Mesh, vacuum
+    if callable(obj):
+        obj = obj()
     if isinstance(obj, Geometry):
         geometry = obj
     elif isinstance(obj, Solid):
@@ -64,8 +67,8 @@ def create_geometry_from_obj(obj, bvh_name="default", auto_build_bvh=True, read_
 def load_geometry_from_string(geometry_str, auto_build_bvh=True, read_bvh_cache=True, update_bvh_cache=True,
                               cache_dir=None, cuda_device=None):
     """A flattened geometry with its BVH from one of the reference's geometry strings (chroma/loader.py:13-137):
-    ``"file.stl[.bz2][:bvh]"`` (a mesh on disk, vacuum inside and out), ``"@module.function[:bvh]"`` (called
-    without arguments; returns a Geometry, Solid or Mesh; the current directory is importable too),
+    ``"file.stl[.bz2][:bvh]"`` (a mesh on disk, vacuum inside and out), ``"@module.name[:bvh]"`` (a Geometry, Solid or Mesh, or a
+    function that returns one when called without arguments; the current directory is importable too),
     ``"name[:bvh]"`` (a geometry saved in the cache under that name) and ``""`` (the cache's default geometry).
     ``cuda_device`` is accepted for compatibility: the BVH is built on the host."""
     geometry_id, _, bvh_name = geometry_str.partition(':')
@@ -80,7 +83,7 @@ def load_geometry_from_string(geometry_str, auto_build_bvh=True, read_bvh_cache=
             module = importlib.import_module(module_name)
         finally:
             sys.path[:] = saved
-        return create_geometry_from_obj(getattr(module, function_name)(), **kw)
+        return create_geometry_from_obj(getattr(module, function_name), **kw)
     if os.path.exists(geometry_id) and geometry_id.lower().endswith(('.stl', '.bz2')):
         from chroma_amd.stl import mesh_from_stl
         from chroma_amd.geometry import Geometry, Solid, vacuum

@@ -40,6 +40,25 @@ def test_loader_uses_and_fills_the_cache(tmp_path):
         load_geometry_from_string('no_such_geometry', cache_dir=str(tmp_path))
 
 
+def test_loader_takes_module_level_objects_as_well_as_functions(tmp_path, monkeypatch):
+    """chroma/loader.py:166 calls the named attribute only ``if callable(obj)``: a module-level Mesh, Solid or
+    Geometry is a valid "@module.name" too."""
+    (tmp_path / 'my_geometry_module.py').write_text(
+        'from chroma_amd.make import cube\n'
+        'from chroma_amd.geometry import Solid, vacuum\n'
+        'a_mesh = cube(10.0)\n'
+        'a_solid = Solid(cube(20.0), vacuum, vacuum)\n'
+        'def a_function():\n'
+        '    return cube(30.0)\n')
+    monkeypatch.chdir(tmp_path)                      # (the current directory is importable, chroma/loader.py:152)
+    sizes = {}
+    for name in ('a_mesh', 'a_solid', 'a_function'):
+        geo = load_geometry_from_string('@my_geometry_module.' + name, cache_dir=str(tmp_path / 'cache'))
+        assert geo.bvh is not None and len(geo.mesh.triangles) > 0
+        sizes[name] = float(np.ptp(geo.mesh.vertices[:, 0]))
+    assert sizes == {'a_mesh': 10.0, 'a_solid': 20.0, 'a_function': 30.0}
+
+
 def _write_stl(path, mesh, binary):
     import bz2
     import struct

@@ -199,6 +199,13 @@ def test_index_checks_reject_a_tampered_tree():
         # a record naming a triangle outside the mesh; a triangle whose record names another one
         assert not _lib.wide_validate(tampered(record_to_tri=lambda a: a.__setitem__(3, ntri)), ntri)
         assert not _lib.wide_validate(tampered(tri_to_record=lambda a: a.__setitem__(0, a[1])), ntri)
+        # an EMPTY child word over a real box (the default walk tells an empty entry by its inverted box alone and
+        # would take the word for leaf record 0x7FFFFFFF); a non-empty entry whose box is inverted
+        empty = np.flatnonzero(ent[:, 3] == EMPTY)
+        assert len(empty) and (ent[empty, :3] == 0x0000FFFF).all()
+        assert not _lib.wide_validate(tampered(wnodes=lambda a: a.reshape(-1, 4).__setitem__((empty[0], 0), 0x00100000)), ntri)
+        assert not _lib.wide_validate(tampered(wnodes=lambda a: a.reshape(-1, 4).__setitem__((leaf[3], 3), EMPTY)), ntri)
+        assert not _lib.wide_validate(tampered(wnodes=lambda a: a.reshape(-1, 4).__setitem__((leaf[3], 1), 0x0000FFFF)), ntri)
         # fewer records than triangles (the record table would be shorter than the ids the kernels read)
         short = tampered()
         short['record_to_tri'] = short['record_to_tri'][:-1]

@@ -55,7 +55,7 @@ for origin in ([0, 0, 0], [300.0, -200.0, 150.0], [0.0, 0.0, 1200.0]):
     ph = Photons(np.tile(np.asarray(origin, dtype=float), (len(d), 1)), d, pol, np.full(len(d), 400.0))
     rs = gpu.get_rng_states(64, seed=77)
     gp = gpu.GPUPhotons(ph)
-    cur, ctr = ph, None
+    cur, ctr, ctr_before = ph, None, None
     for step in range(100):
         before = cur
         gp.propagate(gg, rs, max_steps=1)
