@@ -394,6 +394,23 @@ def main():
     except Exception:
         pass
 
+    # ---- the exact walk's rate (one extra UNTIMED-for-the-headline batch): the reference's own traversal loop for every
+    # ray (chroma_set_walk LITERAL, GPUPhotons.propagate(exact=True)) on the same batch, same step definition
+    exact_rate = None
+    if rank == 0 and not os.environ.get('CHROMA_BENCH_NO_EXACT') and os.environ.get('CHROMA_WALK', 'quad') == 'quad':
+        ctx.set_walk('literal')
+        try:
+            b = batch_for(0) if not resident else buffers[0].fill(20_000)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            run_step(b, False, {})
+            ctx.synchronize()
+            exact_rate = nphotons / (time.perf_counter() - t0)
+        finally:
+            ctx.set_walk('quad')
+        log('exact (literal reference) walk: %.3g photons/s on one batch (%.1fx slower than the default walk)' % (
+            exact_rate, (value / world) / exact_rate))
+
     cpu_baseline = None
     if run_cpu:
         import oracle
@@ -456,6 +473,7 @@ def main():
                        'inputs': 'resident in HBM' if resident else 'bomb regenerated on the device inside the timed region (memory)',
                        'target_photons_per_s_per_gpu': 2.5e6, 'vs_target': value / world / 2.5e6,
                        'steps_per_photon': steps_pp, 'nodes_per_step': nodes_ps, 'triangle_tests_per_step': tris_ps,
+                       'exact_walk_photons_per_s': exact_rate,
                        'geometry_build_s': t_build, 'geometry_cached': geometry_cached, 'geometry_upload_s': t_upload,
                        'reduction': ('none: one GPU' if world == 1 and not os.environ.get('CHROMA_BENCH_COMM') else
                                      'library RCCL (chroma_allreduce_hits, in place on the device arrays)' if lib_comm else

@@ -49,6 +49,7 @@ def main(argv=None):
     ap.add_argument('--save-photons-beg', action='store_true', help='also write the initial photons of every event (bin/chroma-sim:51-53)')
     ap.add_argument('--save-photons-end', action='store_true', help='also write the final photons of every event (bin/chroma-sim:54-56)')
     ap.add_argument('--track', action='store_true', help='also write every photon\'s state after each step (Simulation(photon_tracking=True))')
+    ap.add_argument('--exact', action='store_true', help='the reference\'s own traversal loop for every ray: its hit triangle on EVERY ray, several times slower (Simulation(exact=True))')
     ap.add_argument('--cache-dir', default=None, help='directory of the BVH cache (off by default)')
     args = ap.parse_args(argv)
 
@@ -60,7 +61,7 @@ def main(argv=None):
     t0 = time.time()
     detector = load_geometry_from_string(args.detector, cache_dir=args.cache_dir)
     print('geometry: %d triangles, BVH %d nodes (%.1f s)' % (len(detector.mesh.triangles), len(detector.bvh.nodes), time.time() - t0))
-    sim = Simulation(detector, seed=args.seed, cuda_device=args.device, geant4_processes=0, photon_tracking=args.track)
+    sim = Simulation(detector, seed=args.seed, cuda_device=args.device, geant4_processes=0, photon_tracking=args.track, exact=args.exact)
     rng = np.random.default_rng(sim.seed)
     events = (bomb_event(args.nphotons, wl, pos, rng) for _ in range(args.nevents))
     out = {'nevents': np.array(args.nevents), 'nphotons': np.array(args.nphotons), 'seed': np.array(sim.seed)}

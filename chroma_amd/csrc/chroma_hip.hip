@@ -1787,12 +1787,15 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const float4 *work_in
 // Second pass for the rays the fast walks hand over (their queue slots are listed in retry_list):
 // 1/d not moderate, a winner that is not regular (record_hit_is_regular), a stack deeper than the spill.
 // They take the literal reference walk, intersect_mesh_strict.  ~1e-4 of the rays.
-template <bool COUNT>
+// ALL (the walk CHROMA_WALK_LITERAL): every queued ray takes the literal walk -- the one mode whose answer is the
+// reference's on EVERY ray, the erratic Moeller-Trumbore hits of DESIGN.md section 3.1 included, because nothing about
+// the order of box and triangle tests differs from mesh.h:42-118.  (Slots k_ray_setup settled as NaN keep their entry.)
+template <bool COUNT, bool ALL = false>
 __global__ __launch_bounds__(PROP_BLOCK) void
 k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
                 int32_t *hit_triangle, float *hit_distance, const uint32_t *retry_list, DeviceCounters *counters)
 {
-    const int nretry = (int)st->retry;
+    const int nretry = ALL ? (int)st->n : (int)st->retry;
     __shared__ uint32_t s_lds[TRAV_LDS_WORDS(STACK_LDS, PROP_BLOCK)];
     if (nretry == 0) return;
     LaneCounters cnt = {0, 0, 0, 0};
@@ -1804,11 +1807,15 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
         int slot = 0, last_hit = -1;
         v3 position = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f);
         if (k < nretry) {
-            slot = (int)retry_list[k];
+            slot = ALL ? k : (int)retry_list[k];
             const float4 *r = rays + 4 * (size_t)slot;
             const float4 r0 = r[0], r1 = r[1];
             position = mk3(r0.x, r0.y, r0.z); direction = mk3(r1.x, r1.y, r1.z);         // (normalised by k_ray_setup)
             last_hit = __float_as_int(r0.w);
+        }
+        if (ALL) {
+            walk = k < nretry && __float_as_int(rays[4 * (size_t)slot + 1].w) != HIT_NAN;
+        } else if (k < nretry) {
             // a slot k_physics listed because the cheap test could not vouch for the fast walk's winner still holds
             // that winner: the exact question first (the leaf box by the reference's rule, the reference's slab
             // test); only a winner the reference may really miss is walked again
@@ -1871,7 +1878,8 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
     constexpr bool SORT = FULL && (PHYS_SORT != 0);
     __shared__ uint32_t s_class_count[SORT ? PHYS_BLOCK / WAVE : 1][PHYS_CLASSES];
     __shared__ int32_t s_perm[SORT ? PHYS_BLOCK : 1];
-    const int nthreads = fixup ? (int)st->retry : (int)st->n, renorm = (int)st->renorm, renorm_next = st->in_tail ? 0 : 1;
+    // (fixup = 2, the literal walk: every slot, results taken as they are -- every ray took the reference's own loop)
+    const int nthreads = fixup == 1 ? (int)st->retry : (int)st->n, renorm = (int)st->renorm, renorm_next = st->in_tail ? 0 : 1;
     unsigned long long nsteps = 0;
     // the grid is sized for an upper bound of the photon count: blocks stride over the slots
     for (int block_base = blockIdx.x * PHYS_BLOCK; block_base < nthreads; block_base += gridDim.x * PHYS_BLOCK) {
@@ -1918,7 +1926,7 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
         __syncthreads();               // (the tables are rewritten by the next round)
     }
     if (sorted_slot >= 0) {
-        const int slot = fixup ? (int)retry_list[sorted_slot] : sorted_slot;
+        const int slot = fixup == 1 ? (int)retry_list[sorted_slot] : sorted_slot;
         int tri = hit_triangle[slot];
         const float hit_dist = hit_distance[slot];
         float4 w0, w1, w2, w3;
@@ -2665,6 +2673,39 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (need > STACK_LDS + STACK_SCRATCH)
         return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
     const bool have_wide = geom->view.wnodes != nullptr;
+    if (ctx->wide_walk == CHROMA_WALK_LITERAL) {
+        // the reference's own loop for every ray (mesh.h:42-118 as it stands: its tree, its order, its box arithmetic,
+        // every triangle tested the moment its leaf box is entered), then the physics on the results as they are
+        StepState *st = ctx->d_step;
+        hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st,
+                           use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8), first_n);
+        if (ev) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+        unsigned sblocks = (unsigned)std::min<long long>((n_upper + 255) / 256, (long long)ctx->physics_blocks * 4);
+        hipLaunchKernelGGL(k_ray_setup, dim3(sblocks), dim3(256), 0, ctx->stream, geom->view, work_in, st, ctx->rays,
+                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, &st->retry);
+        if (ev) HIP_TRY(hipEventRecord(ev[3], ctx->stream));
+        const unsigned lblocks = (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK, (long long)ctx->persistent_waves);
+        if (ctx->counting)
+            hipLaunchKernelGGL((k_raycast_retry<true, true>), dim3(lblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
+                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
+        else
+            hipLaunchKernelGGL((k_raycast_retry<false, true>), dim3(lblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
+                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
+        if (ev) HIP_TRY(hipEventRecord(ev[1], ctx->stream));
+        unsigned pblocks = (unsigned)std::min<long long>((n_upper + PHYS_BLOCK - 1) / PHYS_BLOCK, (long long)ctx->physics_blocks);
+        DeviceCounters *pc = ctx->counting ? ctx->d_counters : nullptr;
+        if (geom->view.plain_optics != 0)
+            hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
+                               ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
+                               ctx->retry_list, 2, pc, (float4 *)nullptr);
+        else
+            hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
+                               ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
+                               ctx->retry_list, 2, pc, (float4 *)nullptr);
+        if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+        HIP_TRY(hipGetLastError());
+        return CHROMA_OK;
+    }
     const bool pair = ctx->wide_walk == CHROMA_WALK_PAIR && have_wide && geom->wide_stack_need <= PAIR_STACK + COOP_SPILL;
     const bool quad = !pair && (ctx->wide_walk == CHROMA_WALK_QUAD || ctx->wide_walk == CHROMA_WALK_PAIR) && have_wide &&
                       geom->wide_stack_need <= QUAD_STACK + COOP_SPILL;
@@ -2974,7 +3015,8 @@ int chroma_init(int device, chroma_ctx **out)
         ctx->pair_waves = prop.multiProcessorCount * pair_per_cu;
         if (const char *e = getenv("CHROMA_WALK"))
             ctx->wide_walk = !strcmp(e, "reference") ? CHROMA_WALK_REFERENCE : !strcmp(e, "wide") ? CHROMA_WALK_WIDE
-                           : !strcmp(e, "coop") ? CHROMA_WALK_COOP : !strcmp(e, "pair") ? CHROMA_WALK_PAIR : CHROMA_WALK_QUAD;
+                           : !strcmp(e, "coop") ? CHROMA_WALK_COOP : !strcmp(e, "pair") ? CHROMA_WALK_PAIR
+                           : (!strcmp(e, "literal") || !strcmp(e, "exact")) ? CHROMA_WALK_LITERAL : CHROMA_WALK_QUAD;
         if (const char *e = getenv("CHROMA_RAY_CHUNK")) ctx->ray_chunk = std::max(64, atoi(e));
         if (const char *e = getenv("CHROMA_COOP_CHUNK")) ctx->coop_chunk = std::max(8, atoi(e));
         if (const char *e = getenv("CHROMA_TAIL")) {      // coop (default) | split | fused (the lane-per-photon k_propagate)
@@ -3507,7 +3549,8 @@ int chroma_intersect_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthrea
     uint32_t need = geom->stack_need;
     if (need > STACK_LDS + STACK_SCRATCH)
         return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
-    if (geom->view.wnodes && geom->wide_stack_need <= COOP_STACK + COOP_SPILL && ctx->wide_walk != CHROMA_WALK_REFERENCE)
+    if (geom->view.wnodes && geom->wide_stack_need <= COOP_STACK + COOP_SPILL && ctx->wide_walk != CHROMA_WALK_REFERENCE &&
+        ctx->wide_walk != CHROMA_WALK_LITERAL)
         return distance_to_mesh_fast(ctx, geom, nthreads, d_origin, d_direction, d_last_hit, d_distance, d_triangle);
     dim3 grid((unsigned)((nthreads + PROP_BLOCK - 1) / PROP_BLOCK)), block(PROP_BLOCK);
 #define LAUNCH(N, C) hipLaunchKernelGGL((k_distance_to_mesh<N, C>), grid, block, 0, ctx->stream, geom->view, nthreads, \
@@ -3608,7 +3651,7 @@ int chroma_set_walk(chroma_ctx *ctx, int32_t mode)
 {
     if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
     if (mode != CHROMA_WALK_REFERENCE && mode != CHROMA_WALK_WIDE && mode != CHROMA_WALK_COOP && mode != CHROMA_WALK_QUAD &&
-        mode != CHROMA_WALK_PAIR)
+        mode != CHROMA_WALK_PAIR && mode != CHROMA_WALK_LITERAL)
         return set_error(CHROMA_ERR_INVALID, "unknown walk mode %d", mode);
     ctx->wide_walk = mode;
     return CHROMA_OK;

@@ -113,10 +113,24 @@ class GPUPhotons(object):
 
     @profile_if_possible
     def propagate(self, gpu_geometry, rng_states, nthreads_per_block=64, max_blocks=1024, max_steps=10,
-                  use_weights=False, scatter_first=0, track=False, stats=None, time_kernels=False):
+                  use_weights=False, scatter_first=0, track=False, stats=None, time_kernels=False, exact=False):
         """Propagate to termination or ``max_steps``, whichever comes first.  May be called
         repeatedly to single-step.  With ``track=True`` returns (step_photon_ids, step_photons)
-        like the reference (chroma/gpu/photon.py:218-238,258-259)."""
+        like the reference (chroma/gpu/photon.py:218-238,258-259).
+
+        ``exact=True``: every ray takes the reference's own traversal loop (chroma/cuda/mesh.h:42-118 literally; the
+        walk 'literal') for this call -- the reference's triangle on EVERY ray, including the numerically erratic
+        Moeller-Trumbore hits the default nearest-first walk does not reproduce (~2e-6 of rays aimed exactly at mesh
+        features, none in 2.4e8 random photons; include/chroma_hip.h at chroma_set_walk), at several times the cost.
+        (``track=True`` always runs the literal loop: one lane per photon, chroma_propagate_step.)"""
+        if exact and self.ctx.walk != 'literal':
+            previous = self.ctx.walk
+            self.ctx.set_walk('literal')
+            try:
+                return self.propagate(gpu_geometry, rng_states, nthreads_per_block, max_blocks, max_steps, use_weights,
+                                      scatter_first, track, stats, time_kernels)
+            finally:
+                self.ctx.set_walk(previous)
         nphotons = self.pos.size
         lib, ctx = self.ctx._lib, self.ctx
         rng = self._rng(rng_states)

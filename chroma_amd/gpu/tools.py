@@ -6,6 +6,7 @@ This module takes the place of chroma/gpu/tools.py (PyCUDA): ``create_cuda_conte
 ``pycuda.gpuarray.GPUArray`` the propagate path uses (get / set / fill / slicing / size).
 """
 import ctypes
+import os
 import weakref
 
 import numpy as np
@@ -85,9 +86,27 @@ class Context(object):
     def set_counting(self, enabled):
         _lib.check(self._lib.chroma_set_counting(self.handle, 1 if enabled else 0))
 
+    WALKS = {'reference': 0, 'wide': 1, 'coop': 2, 'quad': 3, 'pair': 4, 'literal': 5}
+
     def set_walk(self, mode):
-        """'quad' (default), 'coop', 'wide' or 'reference': how the per-step ray cast walks (same results)."""
-        _lib.check(self._lib.chroma_set_walk(self.handle, {'reference': 0, 'wide': 1, 'coop': 2, 'quad': 3, 'pair': 4}[mode]))
+        """How the per-step ray cast walks.  'quad' (default), 'pair', 'coop', 'wide': the fast walks over the derived
+        8-wide tree -- equal to each other, and to the reference wherever the winning hit lies inside its triangle's
+        leaf box (every geometrically real hit).  'literal' (alias 'exact'): chroma/cuda/mesh.h:42-118 as it stands for
+        every ray -- the reference's answer on EVERY ray, several times slower.  'reference': the reference's tree and
+        order with postponed triangle tests (a cross-check).  See include/chroma_hip.h, chroma_set_walk."""
+        mode = 'literal' if mode == 'exact' else mode
+        _lib.check(self._lib.chroma_set_walk(self.handle, self.WALKS[mode]))
+        self._walk = mode
+
+    @property
+    def walk(self):
+        """The current walk mode (the library's default, or CHROMA_WALK, until set_walk is called)."""
+        w = getattr(self, '_walk', None)
+        if w is None:
+            w = os.environ.get('CHROMA_WALK', 'quad')
+            w = 'literal' if w == 'exact' else w
+            self._walk = w = w if w in self.WALKS else 'quad'
+        return w
 
     def set_tail(self, mode):
         """'coop' (default), 'split' or 'fused': how propagate() finishes -- or, with 'fused', runs -- a batch."""

@@ -21,7 +21,10 @@ def pick_seed():
 
 class Simulation(object):
     def __init__(self, detector, seed=None, cuda_device=None, particle_tracking=False, photon_tracking=False,
-                 geant4_processes=0, nthreads_per_block=64, max_blocks=1024):
+                 geant4_processes=0, nthreads_per_block=64, max_blocks=1024, exact=False):
+        # ``exact``: propagate with the reference's own traversal loop for every ray (GPUPhotons.propagate(exact=True)):
+        # the reference's hit triangle on every ray, several times slower than the default walk
+        self.exact = bool(exact)
         self.detector = detector
         self.nthreads_per_block = nthreads_per_block
         self.max_blocks = max_blocks
@@ -55,7 +58,7 @@ class Simulation(object):
         t_copy = timer()
         tracking = gpu_photons.propagate(self.gpu_geometry, self.rng_states,
                                          nthreads_per_block=self.nthreads_per_block, max_blocks=self.max_blocks,
-                                         max_steps=max_steps, track=self.photon_tracking)
+                                         max_steps=max_steps, track=self.photon_tracking, exact=self.exact)
         t_prop = timer()
         if verbose:
             print('GPU copy took %0.2f s' % (t_copy - t_start))

@@ -399,15 +399,34 @@ int chroma_propagate_stats_read(chroma_ctx *ctx, chroma_propagate_stats *stats);
 /* enable (1) / disable (0) node/triangle visit counting in the propagate kernels */
 int chroma_set_counting(chroma_ctx *ctx, int32_t enabled);
 
-/* Which tree the one-step ray cast walks, and how: the reference-format nodes in the reference's
- * own order, or the derived 8-wide tree with one, eight or four (default) lanes sharing a ray.
- * Results are identical by construction; the switch exists so that tests and benchmarks can show
- * it.  Env CHROMA_WALK=reference|wide|coop|quad sets the initial mode of a context. */
+/* Which tree the one-step ray cast walks, and how.
+ *
+ * The fast walks (QUAD, the default; PAIR, COOP, WIDE) go through the derived 8-wide tree nearest-first.  They agree
+ * with EACH OTHER on every ray, and with the reference (chroma/cuda/mesh.h:42-118) on every ray whose winning
+ * triangle's Moeller-Trumbore hit lies inside that triangle's own leaf box -- i.e. every hit that is geometrically one.
+ * They do NOT reproduce the reference on rays for which mesh.h:82-101 accepts a numerically erratic hit: a ray almost
+ * inside a triangle's plane (determinant above the FLT_EPSILON cut of intersect.h:58 but tiny) can "hit" hundreds of
+ * millimetres in FRONT of the triangle's box; the reference's depth-first order may meet that triangle before any
+ * nearer one and keep the bogus distance, while a nearest-first walk has pruned the box.
+ * Measured: 0 of 2.4e8 random bomb photons on the 10k- and 29k-PMT detectors, ~2e-6 of rays aimed exactly at mesh
+ * vertices / edge midpoints / centroids (profiles/r02/parity_sweep_*.txt; tests/test_gpu_exact_walk.py checks the
+ * invariant "a ray on which QUAD and LITERAL differ is one whose reference hit lies outside its leaf box").
+ *
+ * LITERAL is the reference's loop as it stands -- its tree, its child order, its float box arithmetic, every triangle
+ * tested the moment its leaf box is entered -- for EVERY ray, one ray per lane: the one mode that returns the
+ * reference's triangle on every ray, the erratic ones included; several times slower (bench.py reports its rate as
+ * config.exact_walk_photons_per_s).  GPUPhotons.propagate(exact=True), Simulation(exact=True) and chroma-sim --exact
+ * select it per call.  REFERENCE walks the reference's tree in the reference's order but postpones triangle tests by up
+ * to 8 per lane (a superset of the reference's tests in the same order): a cross-check walk, equal to LITERAL except
+ * where an erratic hit belongs to a triangle the reference had already pruned.  chroma_intersect_mesh /
+ * chroma_distance_to_mesh run the literal loop under both REFERENCE and LITERAL.
+ * Env CHROMA_WALK=literal|reference|wide|coop|quad|pair sets the initial mode of a context. */
 #define CHROMA_WALK_REFERENCE 0
 #define CHROMA_WALK_WIDE      1
 #define CHROMA_WALK_COOP      2
 #define CHROMA_WALK_QUAD      3   /* the wide tree with four lanes per ray, two child entries per lane */
 #define CHROMA_WALK_PAIR      4   /* the wide tree with two lanes per ray, four child entries per lane  */
+#define CHROMA_WALK_LITERAL   5   /* chroma/cuda/mesh.h:42-118 literally, for every ray: exact, slow */
 int chroma_set_walk(chroma_ctx *ctx, int32_t mode);
 
 /* How chroma_propagate finishes a batch and, with FUSED, how it runs it at all (same results; for

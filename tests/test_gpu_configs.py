@@ -256,3 +256,128 @@ def test_c2_the_known_erratic_moller_trumbore_ray(gpu, oracle_mod, c2):
         from test_gpu_ref_mesh import _ref_cast
         rdist, rtri = _ref_cast(ctypes.CDLL(ref_lib), c2.geometry, o, d)
         assert rtri[0] == otri[0] and rdist.view(np.uint32)[0] == odist.view(np.uint32)[0]
+
+
+# ---- the exact (literal) walk: selectable, and what the default walk may differ on is a CHECKED invariant --------
+# the rays tools/parity_sweep.py found in round 2 (profiles/r02/diag_erratic_mt_c3.txt, ..._detector.txt)
+ERRATIC_C3 = [((300.0, -200.0, 150.0), (0.7215774655342102, 0.5825173258781433, 0.3741651177406311)),
+              ((0.0, 0.0, 1200.0), (0.7105749845504761, 0.21008965373039246, 0.6715247631072998)),
+              ((0.0, 0.0, 1200.0), (-0.8305104970932007, 0.011652595363557339, 0.5568810701370239))]
+ERRATIC_C2 = [((300.0, -200.0, 150.0), (0.3109407126903534, 0.7269728183746338, 0.612230658531189))]
+
+
+def _photons_along(rays, copies=1):
+    from chroma_amd.event import Photons
+    o = np.repeat(np.array([r[0] for r in rays], dtype=np.float32), copies, axis=0)
+    d = np.repeat(np.array([r[1] for r in rays], dtype=np.float32), copies, axis=0)
+    pol = np.cross(d, np.roll(d, 1, axis=1) + 1e-3).astype(np.float32)
+    pol /= np.linalg.norm(pol, axis=1)[:, None]
+    return Photons(o, d, pol.astype(np.float32), np.full(len(o), 400.0, dtype=np.float32))
+
+
+def _exact_propagate_matches_the_oracle(gpu, oracle_mod, cfg, rays, what):
+    """GPUPhotons.propagate(exact=True) on the known erratic rays (padded with 20 000 ordinary bomb photons so that the
+    per-step launches run, not only the tail): flags, last_hit_triangles and every float field == the oracle, after
+    one step and to completion; and the default walk really does differ on them (or the pin below would be vacuous)."""
+    from chroma_amd.event import Photons
+    copies = 64                                  # (64 photons along each ray: other draws, some reach the surface)
+    special = _photons_along(rays, copies)
+    filler = oracle_mod.generate_bomb(20000, seed=5, id_base=0)
+    ph = Photons.join([special, filler])
+    n_special = len(special)
+    for max_steps in (1, 100):
+        want, counters, _ = oracle_mod.propagate(cfg.packed, ph, seed=ENGINE_SEED, max_steps=max_steps, nthreads=min(os.cpu_count() or 1, 64))
+        gp = gpu.GPUPhotons(ph)
+        gp.propagate(cfg.gg, gpu.get_rng_states(64, seed=ENGINE_SEED), max_steps=max_steps, exact=True)
+        assert gpu.get_context().walk == 'quad'                       # (the switch holds for the call only)
+        got = gp.get()
+        assert_bit_exact(got, want, '%s, exact walk, max_steps=%d' % (what, max_steps))
+        assert np.array_equal(gp.rng_counters.get(), counters)
+        gp = gpu.GPUPhotons(ph)
+        gp.propagate(cfg.gg, gpu.get_rng_states(64, seed=ENGINE_SEED), max_steps=max_steps)
+        fast = gp.get()
+        differ = np.flatnonzero((fast.last_hit_triangles != want.last_hit_triangles) | (fast.flags != want.flags))
+        assert set(differ.tolist()) <= set(range(n_special)), 'the default walk differs on an ORDINARY photon'
+        if max_steps == 1:
+            # every pinned ray still is one the default walk answers differently (or the pin would be vacuous)
+            assert set((differ // copies).tolist()) == set(range(len(rays))), 'the default walk now agrees on a ray pinned as erratic'
+
+
+def test_c3_exact_walk_on_the_known_erratic_rays(gpu, oracle_mod, c3):
+    _exact_propagate_matches_the_oracle(gpu, oracle_mod, c3, ERRATIC_C3, 'C3 erratic rays')
+
+
+def test_c2_exact_walk_on_the_known_erratic_ray(gpu, oracle_mod, c2):
+    _exact_propagate_matches_the_oracle(gpu, oracle_mod, c2, ERRATIC_C2, 'C2 erratic ray')
+
+
+def _leaf_box_interval(cfg, tri, origin, direction):
+    """[tmin, tmax] of the rays through the reference's leaf boxes (cuda/bvh.cu:149-203: quantise, one quantum down,
+    one up) of triangles ``tri``, in float64."""
+    wc = cfg.geometry.bvh.world_coords
+    org, ws = np.asarray(wc.world_origin, dtype=np.float64), float(wc.world_scale)
+    m = cfg.geometry.mesh
+    v = m.vertices[m.triangles[tri]].astype(np.float64)                 # [n][3][3]
+    qlo = np.floor((v.min(axis=1) - org) / ws)
+    qlo = np.where(qlo > 0, qlo - 1, qlo)
+    qhi = np.floor((v.max(axis=1) - org) / ws) + 1
+    lo, hi = org + qlo * ws, org + qhi * ws
+    with np.errstate(divide='ignore', invalid='ignore'):
+        t0, t1 = (lo - origin) / direction, (hi - origin) / direction
+    tn, tf = np.minimum(t0, t1), np.maximum(t0, t1)
+    return tn.max(axis=1), tf.min(axis=1)
+
+
+def test_c3_aimed_ray_sweep_the_deviation_class_is_a_checked_invariant(gpu, oracle_mod, c3):
+    """tools/parity_sweep.py's aimed-ray sweep for C3 under -m gpu (one origin, 3.6e5 rays at vertices, edge midpoints
+    and centroids of 60 000 triangles -- the sample that held two of round 2's three differing rays):
+      * the LITERAL walk (the exact mode) agrees with the oracle (== the compiled reference, tests/test_gpu_ref_mesh.py)
+        on every ray: triangle and distance bits;
+      * the default QUAD walk may differ ONLY on rays whose reference hit lies outside the leaf box of the triangle it is
+        attributed to -- a Moeller-Trumbore result that is not a geometric hit."""
+    from chroma_amd import _lib
+    from chroma_amd.gpu.tools import to_gpu, GPUArray
+    m = c3.geometry.mesh
+    v, t = m.vertices.astype(np.float64), m.triangles
+    rng = np.random.default_rng(3)
+    for _ in range(2):                                   # (tools/parity_sweep.py drew for two other origins first)
+        rng.choice(len(t), size=60000, replace=False)
+    pick = rng.choice(len(t), size=60000, replace=False)
+    origin = np.array([0.0, 0.0, 1200.0])
+    tri = v[t[pick]]
+    targets = np.concatenate([tri.reshape(-1, 3), 0.5 * (tri[:, 0] + tri[:, 1]), 0.5 * (tri[:, 1] + tri[:, 2]), tri.mean(axis=1)])
+    d = targets - origin
+    d = d[np.linalg.norm(d, axis=1) > 1e-9]
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    o32 = np.tile(origin.astype(np.float32), (len(d), 1))
+    d32 = np.ascontiguousarray(d, dtype=np.float32)
+    n = len(d32)
+    assert n == 360000
+    odist, otri, _ = oracle_mod.distance_to_mesh(c3.packed, o32, d32)
+    ctx = gpu.get_context()
+    d_o, d_d = to_gpu(o32.reshape(-1), ctx), to_gpu(d32.reshape(-1), ctx)
+
+    def cast(walk):
+        ctx.set_walk(walk)
+        try:
+            dist = GPUArray(n, np.float32, ctx).fill(np.float32(-1.0))
+            tr = GPUArray(n, np.int32, ctx).fill(np.int32(-1))
+            _lib.check(ctx._lib.chroma_distance_to_mesh(ctx.handle, c3.gg.handle, n, d_o.ptr, d_d.ptr, dist.ptr, tr.ptr))
+            return tr.get(), dist.get()
+        finally:
+            ctx.set_walk('quad')
+    ltri, ldist = cast('literal')
+    hit = otri >= 0
+    assert np.array_equal(ltri, otri), 'literal walk: %d rays differ from the oracle' % np.count_nonzero(ltri != otri)
+    assert np.array_equal(ldist[hit].view(np.uint32), odist[hit].view(np.uint32))
+    qtri, qdist = cast('quad')
+    differ = np.flatnonzero((qtri != otri) | (hit & (qdist.view(np.uint32) != odist.view(np.uint32))))
+    print('C3 aimed sweep: literal 0 / %d differ, quad %d differ' % (n, len(differ)))
+    assert len(differ) <= 20
+    if len(differ):
+        assert (otri[differ] >= 0).all()                  # the reference "hit" something the fast walk did not take
+        tmin, tmax = _leaf_box_interval(c3, otri[differ], origin, d32[differ].astype(np.float64))
+        th = odist[differ].astype(np.float64)
+        outside = (th < tmin - 1.0) | (th > tmax + 1.0)               # (a millimetre: far beyond any rounding of a real hit)
+        assert outside.all(), 'the default walk differs on a ray whose reference hit IS inside its leaf box: %r' % (
+            list(zip(differ[~outside].tolist(), th[~outside].tolist(), tmin[~outside].tolist(), tmax[~outside].tolist())),)

@@ -51,7 +51,7 @@ def test_streaming_kernels_run_at_full_occupancy(isa_table):
 
 
 def test_every_kernel_of_the_path_is_in_the_table(isa_table):
-    for name in ('k_physics<false>', 'k_physics<true>', 'k_tail_coop<false>', 'k_propagate<24, false>', 'k_raycast_retry<false>', 'k_raycast_wide<false>',
+    for name in ('k_physics<false>', 'k_physics<true>', 'k_tail_coop<false>', 'k_propagate<24, false>', 'k_raycast_retry<false, false>', 'k_raycast_retry<false, true>', 'k_raycast_wide<false>',
                  'k_raycast_persistent<false>', 'k_distance_to_mesh<24, false>', 'k_copy_hits', 'k_daq_reset', 'k_daq_convert'):
         assert name in isa_table, name
     assert isa_table['k_physics<true>']['waves'] >= 4
