@@ -37,6 +37,7 @@ CONFIGS = {
 }
 C4_PHOTONS_PER_GPU = 125_000_000      # configs[3]: 1e9 photons sharded over 8 GPUs
 ENGINE_SEED = 12345
+SORT_DIRECTIONS = os.environ.get('CHROMA_BENCH_SORT', '1') != '0'      # photons in tools.argsort_direction order, as chroma/benchmark.py:80-82
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 RAYCAST_KERNEL = {'reference': 'k_raycast_persistent', 'wide': 'k_raycast_wide', 'coop': 'k_raycast_coop'}.get(os.environ.get('CHROMA_WALK', ''), 'k_raycast_quad')
 
@@ -164,7 +165,8 @@ def main():
         nphotons = C4_PHOTONS_PER_GPU
     desc = desc % ('%.3g' % nphotons)
 
-    # ---- geometry: built once per node, uploaded by every rank ---------------------------------------------
+    # ---- geometry: built once per node (its BVH on the GPU, as in the reference), uploaded by every rank ----------
+    ctx = gpu.create_cuda_context(device_index)
     t0 = time.time()
 
     def build_packed():
@@ -197,7 +199,6 @@ def main():
         'loaded from the geometry cache' if geometry_cached else
         'built + wide tree' if (world == 1 or local_rank == 0) else 'mapped from %s' % shm_path, t_build))
 
-    ctx = gpu.create_cuda_context(device_index)
     t0 = time.time()
     gg = gpu.GPUDetector.from_packed(packed)
     lib_comm = True
@@ -254,6 +255,10 @@ def main():
             self.id_base = (index * world + rank) * nphotons
             pos = (ctypes.c_float * 3)(0.0, 0.0, 0.0)
             _lib.check(lib.chroma_generate_bomb(ctx.handle, ctypes.byref(self.struct), nphotons, ENGINE_SEED, self.id_base, pos, wl_lo, wl_hi))
+            if SORT_DIRECTIONS:
+                # chroma/benchmark.py:80-82: the reference's propagate benchmark puts its photons in the order of
+                # tools.argsort_direction before it starts the clock; same here, on the device
+                _lib.check(lib.chroma_photons_sort_direction(ctx.handle, ctypes.byref(self.struct), nphotons))
             return self
 
     # per-step outputs, allocated once: per-channel arrays and the flat-hit buffers (get_flat_hits' destination)
@@ -470,7 +475,9 @@ def main():
                        'engine_seed': ENGINE_SEED, 'parallelism': 'photon shards x%d, geometry replicated, per-channel arrays all-reduced (%s)' % (
                            world, 'RCCL inside the library' if lib_comm else ('torch.distributed, %s' % (backend if world > 1 else '-'))),
                        'step': 'propagate(max_steps) + channel hit arrays + flat-hit count and compaction' + (' + all-reduce' if world > 1 else ''),
-                       'inputs': 'resident in HBM' if resident else 'bomb regenerated on the device inside the timed region (memory)',
+                       'inputs': ('resident in HBM' if resident else 'bomb regenerated on the device inside the timed region (memory)') +
+                                 ('; photons in the order of tools.argsort_direction (Morton code of theta, phi), as the reference\'s own '
+                                  'propagate benchmark prepares them before its clock starts (chroma/benchmark.py:80-82)' if SORT_DIRECTIONS else '; photons in generation order (unsorted)'),
                        'target_photons_per_s_per_gpu': 2.5e6, 'vs_target': value / world / 2.5e6,
                        'steps_per_photon': steps_pp, 'nodes_per_step': nodes_ps, 'triangle_tests_per_step': tris_ps,
                        'exact_walk_photons_per_s': exact_rate,

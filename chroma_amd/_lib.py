@@ -141,6 +141,9 @@ SIGNATURES = {
     'chroma_probe': (c_int32, [c_void_p, c_int32, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32, c_float, c_float, c_void_p]),
     'chroma_bvh_build': (c_int32, [c_void_p, c_uint32, c_void_p, c_uint32, POINTER(c_float), c_float, c_int32,
                                    POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint32)]),
+    'chroma_bvh_build_device': (c_int32, [c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, POINTER(c_float), c_float, c_int32,
+                                          POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint32)]),
+    'chroma_photons_sort_direction': (c_int32, [c_void_p, POINTER(PhotonArrays), c_uint64]),
     'chroma_bvh_fetch': (c_int32, [c_void_p, c_void_p, c_void_p]),
     'chroma_bvh_data': (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p)]),
     'chroma_bvh_free': (c_int32, [c_void_p]),
@@ -211,19 +214,26 @@ def ptr(arr):
     return arr.ctypes.data_as(c_void_p)
 
 
-def bvh_build(vertices, triangles, world_origin, world_scale, target_degree=3):
-    """Host-side BVH build.  Returns (nodes as structured uint4 array, layer bounds)."""
+def bvh_build(vertices, triangles, world_origin, world_scale, target_degree=3, ctx=None):
+    """BVH build: on the host cores (``ctx`` None: chroma_bvh_build) or on the device of the chroma_amd.gpu context
+    ``ctx`` (chroma_bvh_build_device) -- the same node array bit for bit.  Returns (nodes as structured uint4
+    array, layer bounds)."""
     from chroma_amd.bvh.bvh import uint4
-    lib = load()
+    lib = load() if ctx is None else ctx._lib
     vertices = np.ascontiguousarray(vertices, dtype=np.float32)
     triangles = np.ascontiguousarray(triangles, dtype=np.uint32)
     origin = (c_float * 3)(*[float(x) for x in world_origin])
     handle = c_void_p()
     nnodes = c_uint64()
     nlayers = c_uint32()
-    check(lib.chroma_bvh_build(ptr(vertices), len(vertices), ptr(triangles), len(triangles), origin,
-                               c_float(float(world_scale)), int(target_degree),
-                               ctypes.byref(handle), ctypes.byref(nnodes), ctypes.byref(nlayers)))
+    if ctx is None:
+        check(lib.chroma_bvh_build(ptr(vertices), len(vertices), ptr(triangles), len(triangles), origin,
+                                   c_float(float(world_scale)), int(target_degree),
+                                   ctypes.byref(handle), ctypes.byref(nnodes), ctypes.byref(nlayers)))
+    else:
+        check(lib.chroma_bvh_build_device(ctx.handle, ptr(vertices), len(vertices), ptr(triangles), len(triangles), origin,
+                                          c_float(float(world_scale)), int(target_degree),
+                                          ctypes.byref(handle), ctypes.byref(nnodes), ctypes.byref(nlayers)), lib)
     # view the builder's own buffer (no copy); it is released when the array is garbage-collected
     p_nodes, p_bounds = c_void_p(), c_void_p()
     check(lib.chroma_bvh_data(handle, ctypes.byref(p_nodes), ctypes.byref(p_bounds)))

@@ -8,10 +8,12 @@ until the mean group size reaches ``target_degree``, make one parent per run of 
 codes, split runs longer than 15, union the child boxes.  Finally layers are
 concatenated root first and single-child chains are collapsed.
 
-The reference needs a CUDA context for this; here the work is done by the native
-builder in libchroma_hip.so (``backend='native'``, multi-threaded host C++) with a
-NumPy restatement (``backend='numpy'``) kept as an independent cross-check: the
-two must return identical node arrays (tests/test_bvh.py).
+The reference needs a CUDA context for this.  Here there are three builders that must
+return identical node arrays: HIP kernels on the device (``backend='device'``,
+csrc/bvh_device.hip: the default when a GPU is there, as in the reference), the same
+algorithm on the host cores (``backend='native'``, multi-threaded C++ in libchroma_hip.so)
+and a NumPy restatement (``backend='numpy'``) kept as an independent cross-check
+(tests/test_bvh.py, tests/test_gpu_bvh.py).
 """
 import numpy as np
 
@@ -124,21 +126,45 @@ def _build_numpy(vertices, triangles, world_coords, target_degree):
     return nodes, bounds
 
 
-def make_recursive_grid_bvh(mesh, target_degree=3, verbose=False, backend='native'):
-    """BVH of ``mesh`` (chroma/bvh/grid.py:11).  ``backend``: 'native' | 'numpy'."""
+def _device_context():
+    """The current chroma_amd.gpu context, or a new one on device 0 when the machine has a GPU; None otherwise."""
+    try:
+        from chroma_amd.gpu import tools as gtools
+        if gtools._current is not None:
+            return gtools._current
+        if gtools.device_count() > 0:
+            return gtools.get_context()
+    except Exception:
+        pass
+    return None
+
+
+def make_recursive_grid_bvh(mesh, target_degree=3, verbose=False, backend=None):
+    """BVH of ``mesh`` (chroma/bvh/grid.py:11).  ``backend``: 'device' (HIP kernels on the current context's GPU, as
+    in the reference, where these steps are CUDA kernels), 'native' (the same algorithm on the host cores), 'numpy'
+    (the independent restatement); None = $CHROMA_BVH_BACKEND, else 'device' when a GPU is there and 'native'
+    otherwise.  All three return the same node array bit for bit."""
+    import os
     vertices = np.ascontiguousarray(mesh.vertices, dtype=np.float32)
     triangles = np.ascontiguousarray(mesh.triangles, dtype=np.uint32)
     if len(triangles) >= 2 ** CHILD_BITS:
         raise ValueError('mesh has too many triangles for 28-bit child indices')
     world_coords = world_coords_for(vertices)
-    if backend == 'native':
+    backend = backend or os.environ.get('CHROMA_BVH_BACKEND') or 'auto'
+    ctx = None
+    if backend in ('auto', 'device'):
+        ctx = _device_context()
+        if ctx is None and backend == 'device':
+            raise RuntimeError("backend='device' needs a GPU (chroma_amd.gpu.create_cuda_context)")
+        backend = 'native' if ctx is None else 'device'
+    if backend in ('native', 'device'):
         from chroma_amd import _lib
         nodes, bounds = _lib.bvh_build(vertices, triangles, world_coords.world_origin,
-                                       world_coords.world_scale, target_degree)
+                                       world_coords.world_scale, target_degree, ctx=ctx)
     elif backend == 'numpy':
         nodes, bounds = _build_numpy(vertices, triangles, world_coords, target_degree)
     else:
         raise ValueError('unknown backend %r' % backend)
     if verbose:
-        print('BVH: %d nodes, layers %s' % (len(nodes), list(np.diff(bounds))))
+        print('BVH (%s): %d nodes, layers %s' % (backend, len(nodes), list(np.diff(bounds))))
     return BVH(world_coords, nodes, [int(b) for b in bounds[:-1]])

@@ -18,6 +18,7 @@
 
 #include "../../include/chroma_hip.h"
 #include "host_utils.h"
+#include "bvh_result.h"
 
 namespace {
 struct Timer {
@@ -30,13 +31,9 @@ struct Timer {
     }
 };
 
-struct Node { uint32_t x, y, z, w; };
+using chroma_host::Node;
+using chroma_host::BvhResult;
 const int MAX_CHILD = 15;   // 2^(32-28) - 1, chroma/bvh/grid.py:6
-
-struct BvhResult {
-    std::vector<Node> nodes;
-    std::vector<uint64_t> layer_bounds;   // nlayers + 1 entries
-};
 
 inline uint64_t spread3_16(uint32_t input)   // cuda/bvh.cu:42-52
 {

@@ -38,6 +38,18 @@ static int set_error(int code, const char *fmt, ...)
     return code;
 }
 
+#include "ctx_access.h"
+extern "C" int chroma_internal_set_error(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -95,6 +107,9 @@ struct chroma_ctx {
     uint32_t *gather_buf = nullptr;        // [comm_nranks][n] words for the OR reduction (all-gather + local OR)
     size_t gather_capacity = 0;
 };
+
+extern "C" hipStream_t chroma_internal_stream(chroma_ctx *ctx) { return ctx->stream; }
+extern "C" int chroma_internal_device(chroma_ctx *ctx) { return ctx->device; }
 
 struct chroma_geometry {
     chroma_ctx *ctx;

@@ -253,6 +253,15 @@ class GPUPhotons(object):
                                            ctypes.byref(src), counts.ptr, earliest.ptr))
         return counts, earliest
 
+    def sort_by_direction(self):
+        """Put the photons in the order of tools.argsort_direction (chroma/tools.py:175-193: a Morton code of theta
+        and phi of their directions), on the device -- what the reference's benchmark does to its photons before it
+        starts the clock (chroma/benchmark.py:80-82), so that neighbouring photons take neighbouring paths.  Every
+        array of the set is reordered; slot i then holds the photon of rank i (random streams stay keyed by slot)."""
+        s = _structure(self)
+        _lib.check(self.ctx._lib.chroma_photons_sort_direction(self.ctx.handle, ctypes.byref(s), self.pos.size))
+        return self
+
     def iterate_copies(self):
         """GPUPhotonsSlice views of the ``ncopies`` replicas."""
         for i in range(self.ncopies):

@@ -312,6 +312,12 @@ int chroma_generate_bomb(chroma_ctx *ctx, const chroma_photon_arrays *photons, u
                          uint64_t seed, uint64_t id_base, const float pos[3],
                          float wavelength_lo, float wavelength_hi);
 
+/* tools.argsort_direction (chroma/tools.py:175-193) and the reordering it serves, for a photon set on the device: the
+ * photons are put in the order of a 32-bit Morton code of (theta, phi) of their directions (stable), every array of
+ * the set gathered accordingly.  The reference's own benchmark does this to its photons before it starts the clock
+ * (chroma/benchmark.py:80-82); bench.py does the same to its bomb.  Slot i afterwards holds the photon of rank i. */
+int chroma_photons_sort_direction(chroma_ctx *ctx, const chroma_photon_arrays *photons, uint64_t nphotons);
+
 /* `render` (chroma/cuda/render.cu:37-181): every triangle along each ray, the `alpha_depth` nearest kept as
  * a per-ray list sorted by distance (d_dx [n][alpha_depth], d_color [n][alpha_depth][4], d_dxlen [n]: in and
  * out, so that a second call continues the first -- GPURays.render(keep_last_render=True)), composited
@@ -359,6 +365,14 @@ int chroma_probe(chroma_ctx *ctx, int32_t fn, uint64_t n, const float *d_x, cons
 int chroma_bvh_build(const float *vertices, uint32_t nvertices, const uint32_t *triangles, uint32_t ntriangles,
                      const float world_origin[3], float world_scale, int32_t target_degree,
                      void **handle, uint64_t *nnodes, uint32_t *nlayers);
+/* The same builder ON THE DEVICE of `ctx` (csrc/bvh_device.hip), as in the reference, where these steps ARE device
+ * kernels: leaf boxes + 48-bit Morton codes (bvh.cu:149-203), a device radix sort (grid.py:26-28), group boundaries by
+ * one histogram pass and two scans (grid.py:37-76), parent unions per layer (bvh.cu:270-308), concatenate + offset
+ * (bvh.cu:365-384), collapse (bvh.cu:530-543).  Host arrays in, the same kind of handle out, and the SAME node array
+ * bit for bit as chroma_bvh_build (tests/test_gpu_bvh.py). */
+int chroma_bvh_build_device(chroma_ctx *ctx, const float *vertices, uint32_t nvertices, const uint32_t *triangles,
+                            uint32_t ntriangles, const float world_origin[3], float world_scale, int32_t target_degree,
+                            void **handle, uint64_t *nnodes, uint32_t *nlayers);
 int chroma_bvh_fetch(void *handle, uint32_t *nodes_out, uint64_t *layer_bounds_out);
 /* zero-copy access to the arrays owned by the handle (valid until chroma_bvh_free) */
 int chroma_bvh_data(void *handle, const uint32_t **nodes, const uint64_t **layer_bounds);

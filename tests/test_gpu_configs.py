@@ -381,3 +381,27 @@ def test_c3_aimed_ray_sweep_the_deviation_class_is_a_checked_invariant(gpu, orac
         outside = (th < tmin - 1.0) | (th > tmax + 1.0)               # (a millimetre: far beyond any rounding of a real hit)
         assert outside.all(), 'the default walk differs on a ray whose reference hit IS inside its leaf box: %r' % (
             list(zip(differ[~outside].tolist(), th[~outside].tolist(), tmin[~outside].tolist(), tmax[~outside].tolist())),)
+
+
+# ---- a-20 at full size: the geometries above were built with the DEVICE builder (the default with a GPU) ------------
+def _device_bvh_equals_host(cfg, what):
+    from chroma_amd.bvh.grid import make_recursive_grid_bvh
+    import time
+    t0 = time.time()
+    host = make_recursive_grid_bvh(cfg.geometry.mesh, backend='native')
+    t1 = time.time()
+    dev = make_recursive_grid_bvh(cfg.geometry.mesh, backend='device')
+    t2 = time.time()
+    print('%s: %d nodes; host builder %.1f s, device builder %.1f s (incl. world frame, upload, download)' % (what, len(host.nodes), t1 - t0, t2 - t1))
+    assert np.array_equal(dev.nodes.view(np.uint32), host.nodes.view(np.uint32))
+    assert dev.layer_offsets == host.layer_offsets
+    # and the one the fixture's geometry carries (built by the default backend: the device)
+    assert np.array_equal(np.ascontiguousarray(cfg.geometry.bvh.nodes).view(np.uint32), host.nodes.view(np.uint32))
+
+
+def test_c2_device_bvh_equals_the_host_builder(gpu, c2):
+    _device_bvh_equals_host(c2, 'C2 demo.detector()')
+
+
+def test_c3_device_bvh_equals_the_host_builder(gpu, c3):
+    _device_bvh_equals_host(c3, 'C3 29k PMTs')
