@@ -96,6 +96,9 @@ SIGNATURES = {
     'chroma_malloc': (c_int32, [c_void_p, c_size_t, POINTER(c_void_p)]),
     'chroma_free': (c_int32, [c_void_p, c_void_p]),
     'chroma_memcpy_htod': (c_int32, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'chroma_upload': (c_int32, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    'chroma_pool_trim': (c_int32, [c_void_p]),
+    'chroma_pool_stats': (c_int32, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     'chroma_memcpy_dtoh': (c_int32, [c_void_p, c_void_p, c_void_p, c_size_t]),
     'chroma_memcpy_dtod': (c_int32, [c_void_p, c_void_p, c_void_p, c_size_t]),
     'chroma_memset32': (c_int32, [c_void_p, c_void_p, c_uint32, c_size_t]),

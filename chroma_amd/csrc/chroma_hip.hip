@@ -14,6 +14,9 @@
 #include <algorithm>
 #include <chrono>
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
+#include <map>
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>          // types and prototypes only: RCCL itself is found with dlopen at first use
@@ -106,6 +109,21 @@ struct chroma_ctx {
     int comm_nranks = 1, comm_rank = 0;
     uint32_t *gather_buf = nullptr;        // [comm_nranks][n] words for the OR reduction (all-gather + local OR)
     size_t gather_capacity = 0;
+    // ---- device-memory pool behind chroma_malloc / chroma_free (see there) ----
+    struct PoolBlock { void *ptr; hipEvent_t ev; };
+    std::mutex pool_mu;
+    std::multimap<size_t, PoolBlock> pool;                 // free blocks by size
+    std::unordered_map<void *, size_t> live;               // size of every block handed out
+    std::vector<hipEvent_t> pool_events;                   // spare events
+    size_t pool_bytes = 0, pool_limit = 0;
+    uint64_t pool_hits = 0, pool_misses = 0;
+    // ---- host -> device uploads: a second stream and a ring of pinned staging buffers (chroma_upload) ----
+    hipStream_t copy_stream = nullptr;
+    std::mutex stage_mu;
+    static constexpr int STAGE_N = 3;
+    static constexpr size_t STAGE_BYTES = 32u << 20;
+    void *stage[STAGE_N] = {nullptr, nullptr, nullptr};
+    hipEvent_t stage_ev[STAGE_N] = {nullptr, nullptr, nullptr};
 };
 
 extern "C" hipStream_t chroma_internal_stream(chroma_ctx *ctx) { return ctx->stream; }
@@ -1860,7 +1878,9 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
     if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
 }
 
+#ifndef PHYS_BLOCK
 #define PHYS_BLOCK 512
+#endif
 #ifndef PHYS_WAVES_PER_EU
 #define PHYS_WAVES_PER_EU 4
 #endif
@@ -1869,10 +1889,14 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
 #endif
 #define PHYS_CLASSES 8
 #ifndef PHYS_PLAIN_WAVES_PER_EU
-#define PHYS_PLAIN_WAVES_PER_EU 4
+#define PHYS_PLAIN_WAVES_PER_EU 5   // 96 VGPRs, no scratch (round 3: the photon's record is asked for together with its hit entry);
+#endif                              // five waves per SIMD need blocks of FOUR waves -- 20 waves per CU are five such blocks, but only two of eight
+#ifndef PHYS_PLAIN_BLOCK
+#define PHYS_PLAIN_BLOCK 256        // -2 ms per C3 step against 512 threads at 4 waves (profiles/r03/ab_physics_occupancy.txt)
 #endif
+#define PHYS_BLOCK_OF(FULL) ((FULL) ? PHYS_BLOCK : PHYS_PLAIN_BLOCK)
 template <bool FULL>
-__global__ __launch_bounds__(PHYS_BLOCK) __attribute__((amdgpu_waves_per_eu(FULL ? PHYS_WAVES_PER_EU : PHYS_PLAIN_WAVES_PER_EU))) void
+__global__ __launch_bounds__(PHYS_BLOCK_OF(FULL)) __attribute__((amdgpu_waves_per_eu(FULL ? PHYS_WAVES_PER_EU : PHYS_PLAIN_WAVES_PER_EU))) void
 k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32_t *output_queue, float4 *work_out,
           const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base,
           int use_weights, int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters, float4 *rays_next)
@@ -1883,7 +1907,8 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
     // after k_raycast_retry has walked those rays the reference's way: the listed slots only, results
     // taken as they are.  A photon that survives the step is appended to the next working set; one that
     // ends here is written to the caller's arrays (the only time they are touched).
-    __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
+    constexpr int BLOCK = PHYS_BLOCK_OF(FULL);
+    __shared__ uint32_t s_counts[BLOCK / WAVE + 1];
     // The 512 slots of a round are dealt to the threads BY THE SURFACE THEY HIT (the material code of the winning
     // triangle's record): what a photon does at a black wall, at PMT glass, at the photocathode, at a mirror, a thin
     // film or a wavelength shifter are different, long branches, and a wave that holds all kinds executes them all.
@@ -1891,13 +1916,13 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
     // build only (-8 % at C5): with plain optics the step's divergence is in the bulk, not at the surface, and the four
     // barriers and the extra gather of the sort cost 2 ms per C3 step (profiles/r02/ab_physics_sort.txt).
     constexpr bool SORT = FULL && (PHYS_SORT != 0);
-    __shared__ uint32_t s_class_count[SORT ? PHYS_BLOCK / WAVE : 1][PHYS_CLASSES];
-    __shared__ int32_t s_perm[SORT ? PHYS_BLOCK : 1];
+    __shared__ uint32_t s_class_count[SORT ? BLOCK / WAVE : 1][PHYS_CLASSES];
+    __shared__ int32_t s_perm[SORT ? BLOCK : 1];
     // (fixup = 2, the literal walk: every slot, results taken as they are -- every ray took the reference's own loop)
     const int nthreads = fixup == 1 ? (int)st->retry : (int)st->n, renorm = (int)st->renorm, renorm_next = st->in_tail ? 0 : 1;
     unsigned long long nsteps = 0;
     // the grid is sized for an upper bound of the photon count: blocks stride over the slots
-    for (int block_base = blockIdx.x * PHYS_BLOCK; block_base < nthreads; block_base += gridDim.x * PHYS_BLOCK) {
+    for (int block_base = blockIdx.x * BLOCK; block_base < nthreads; block_base += gridDim.x * BLOCK) {
     int id = block_base + threadIdx.x;
     bool alive = false;
     uint32_t photon_id = 0;
@@ -1926,9 +1951,9 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
         }
         __syncthreads();
         // start of (class, wave) in the sorted order -- classes in order, waves within a class: one wave scans the 64 counts
-        static_assert(PHYS_CLASSES * (PHYS_BLOCK / WAVE) == WAVE, "one lane per (class, wave) pair");
+        static_assert(!SORT || PHYS_CLASSES * (BLOCK / WAVE) == WAVE, "one lane per (class, wave) pair");
         if (wave == 0) {
-            const uint32_t c = lane / (PHYS_BLOCK / WAVE), w = lane % (PHYS_BLOCK / WAVE);
+            const uint32_t c = lane / (BLOCK / WAVE), w = lane % (BLOCK / WAVE);
             const uint32_t k = s_class_count[w][c];
             uint32_t incl = k;
             for (int off = 1; off < WAVE; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
@@ -1942,12 +1967,13 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
     }
     if (sorted_slot >= 0) {
         const int slot = fixup == 1 ? (int)retry_list[sorted_slot] : sorted_slot;
+        // (the photon's record is asked for TOGETHER with its hit entry, not after it: one memory latency less in the
+        //  chain of a round; the few slots that turn out to be HIT_RETRY read 64 bytes for nothing)
+        const float4 *w = work_in + 4 * (size_t)slot;
+        const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
         int tri = hit_triangle[slot];
         const float hit_dist = hit_distance[slot];
-        float4 w0, w1, w2, w3;
         if (tri != HIT_RETRY) {
-            const float4 *w = work_in + 4 * (size_t)slot;
-            w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3];
             photon_id = __float_as_uint(w3.w);
             p.position = mk3(w0.x, w0.y, w0.z);
             p.direction = mk3(w1.x, w1.y, w1.z);
@@ -2008,7 +2034,7 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
             }
         }
     }
-    const uint32_t at = block_queue_append<PHYS_BLOCK / WAVE>(output_queue, alive, photon_id, s_counts);
+    const uint32_t at = block_queue_append<BLOCK / WAVE>(output_queue, alive, photon_id, s_counts);
     if (alive) {
         float4 *w = work_out + 4 * (size_t)(at - 1u);
         w[0] = make_float4(p.position.x, p.position.y, p.position.z, p.wavelength);
@@ -2707,10 +2733,11 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
             hipLaunchKernelGGL((k_raycast_retry<false, true>), dim3(lblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
         if (ev) HIP_TRY(hipEventRecord(ev[1], ctx->stream));
-        unsigned pblocks = (unsigned)std::min<long long>((n_upper + PHYS_BLOCK - 1) / PHYS_BLOCK, (long long)ctx->physics_blocks);
+        const int pb = PHYS_BLOCK_OF(geom->view.plain_optics == 0);
+        unsigned pblocks = (unsigned)std::min<long long>((n_upper + pb - 1) / pb, (long long)ctx->physics_blocks * (PHYS_BLOCK / pb));
         DeviceCounters *pc = ctx->counting ? ctx->d_counters : nullptr;
         if (geom->view.plain_optics != 0)
-            hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
+            hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK_OF(false)), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                                ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
                                ctx->retry_list, 2, pc, (float4 *)nullptr);
         else
@@ -2778,11 +2805,12 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (ctx->counting) RAYCAST_LAUNCH(true); else RAYCAST_LAUNCH(false);
 #undef RAYCAST_LAUNCH
     // physics for every slot whose hit is regular; then the strict walk and the physics of the rest
-    unsigned pblocks = (unsigned)std::min<long long>((n_upper + PHYS_BLOCK - 1) / PHYS_BLOCK, (long long)ctx->physics_blocks);
-    DeviceCounters *pc = ctx->counting ? ctx->d_counters : nullptr;
     const bool plain = geom->view.plain_optics != 0;      // (no re-emitting component, default surface model only)
+    const int pb = PHYS_BLOCK_OF(!plain);
+    unsigned pblocks = (unsigned)std::min<long long>((n_upper + pb - 1) / pb, (long long)ctx->physics_blocks * (PHYS_BLOCK / pb));
+    DeviceCounters *pc = ctx->counting ? ctx->d_counters : nullptr;
     if (plain)
-        hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
+        hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK_OF(false)), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                            ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
                            ctx->retry_list, 0, pc, rays_next);
     else
@@ -2798,12 +2826,15 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     else
         hipLaunchKernelGGL((k_raycast_retry<false>), dim3(rblocks), block, 0, ctx->stream, geom->view, ctx->rays, st,
                            ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
+    // (the list is ~1e-3 of the slots with plain optics: an eighth of the grid strides over it in a round or two, and a
+    //  launch of 2048 blocks that find nothing to do costs 0.07 ms, 29 times per batch)
+    const unsigned fblocks = plain ? std::max(std::min(pblocks, 64u), pblocks / 8) : pblocks;
     if (plain)
-        hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
+        hipLaunchKernelGGL((k_physics<false>), dim3(fblocks), dim3(PHYS_BLOCK_OF(false)), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
                            work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
                            scatter_first, ctx->retry_list, 1, pc, rays_next);
     else
-        hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
+        hipLaunchKernelGGL((k_physics<true>), dim3(fblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
                            work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
                            scatter_first, ctx->retry_list, 1, pc, rays_next);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
@@ -3001,6 +3032,13 @@ int chroma_init(int device, chroma_ctx **out)
     chroma_ctx *ctx = new chroma_ctx;
     ctx->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        ctx->pool_limit = (size_t)(0.4 * (double)total_b);
+        if (const char *e = getenv("CHROMA_POOL_MB")) ctx->pool_limit = (size_t)std::max(0ll, atoll(e)) << 20;
+    }
     HIP_TRY(hipMalloc((void **)&ctx->d_counters, sizeof(DeviceCounters)));
     HIP_TRY(hipMemset(ctx->d_counters, 0, sizeof(DeviceCounters)));
     HIP_TRY(hipMalloc((void **)&ctx->d_words, 16 * sizeof(uint32_t)));
@@ -3015,7 +3053,7 @@ int chroma_init(int device, chroma_ctx **out)
         int per_cu = 20;                     // LDS-limited residency of k_raycast_persistent (8 KB per wave)
         if (const char *e = getenv("CHROMA_RAY_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));
         ctx->persistent_waves = prop.multiProcessorCount * per_cu;
-        ctx->physics_blocks = prop.multiProcessorCount * 8;
+        ctx->physics_blocks = prop.multiProcessorCount * 8;          // (for blocks of PHYS_BLOCK threads)
         int wide_per_cu = 14;                // LDS-limited residency of k_raycast_wide
         if (const char *e = getenv("CHROMA_WIDE_WAVES_PER_CU")) wide_per_cu = std::max(1, atoi(e));
         ctx->wide_waves = prop.multiProcessorCount * wide_per_cu;
@@ -3046,12 +3084,17 @@ int chroma_init(int device, chroma_ctx **out)
     return CHROMA_OK;
 }
 
+static void pool_release_all(chroma_ctx *ctx);
 int chroma_shutdown(chroma_ctx *ctx)
 {
     if (!ctx) return CHROMA_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->copy_stream);
     chroma_comm_destroy(ctx);
+    { std::lock_guard<std::mutex> lock(ctx->pool_mu); pool_release_all(ctx); for (hipEvent_t e : ctx->pool_events) hipEventDestroy(e); ctx->pool_events.clear(); }
+    for (int i = 0; i < chroma_ctx::STAGE_N; i++) { if (ctx->stage[i]) hipHostFree(ctx->stage[i]); if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]); }
+    hipStreamDestroy(ctx->copy_stream);
     if (ctx->queue_a) hipFree(ctx->queue_a);
     if (ctx->queue_b) hipFree(ctx->queue_b);
     if (ctx->wide_spill) hipFree(ctx->wide_spill);
@@ -3104,18 +3147,121 @@ int chroma_device_name(chroma_ctx *ctx, char *buf, size_t buflen)
     return CHROMA_OK;
 }
 
+// ---- device memory: a pool -----------------------------------------------------------------------------------
+// Simulation builds a GPUPhotons per event batch: ten arrays allocated, used for one propagate, dropped.  hipMalloc and
+// hipFree each cost ~0.1-1 ms for blocks of hundreds of MB and hipFree synchronises the device, so blocks are kept
+// instead: chroma_free parks a block (with an event recorded on the context's stream: work already queued on it may
+// still use the block), chroma_malloc hands a parked block of exactly the requested size back once that event has
+// completed -- no waiting, no new allocation.  Capped at CHROMA_POOL_MB (default: 40 % of the device's memory);
+// chroma_pool_trim releases everything parked (also done by itself when hipMalloc runs out of memory).
+static size_t pool_round(size_t nbytes) { return (std::max(nbytes, (size_t)4) + 255) & ~(size_t)255; }
+
+static void pool_release_all(chroma_ctx *ctx)       // (pool_mu held)
+{
+    for (auto &kv : ctx->pool) { hipEventSynchronize(kv.second.ev); hipFree(kv.second.ptr); ctx->pool_events.push_back(kv.second.ev); }
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+}
+
 int chroma_malloc(chroma_ctx *ctx, size_t nbytes, void **d_ptr)
 {
     if (!ctx || !d_ptr) return set_error(CHROMA_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMalloc(d_ptr, std::max(nbytes, (size_t)4)));
+    const size_t size = pool_round(nbytes);
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    auto range = ctx->pool.equal_range(size);
+    for (auto it = range.first; it != range.second; ++it) {
+        if (hipEventQuery(it->second.ev) != hipSuccess) continue;          // still in use by queued work
+        *d_ptr = it->second.ptr;
+        ctx->pool_events.push_back(it->second.ev);
+        ctx->pool.erase(it);
+        ctx->pool_bytes -= size;
+        ctx->live[*d_ptr] = size;
+        ctx->pool_hits++;
+        return CHROMA_OK;
+    }
+    (void)hipGetLastError();                                               // (hipEventQuery's hipErrorNotReady is not an error)
+    hipError_t e = hipMalloc(d_ptr, size);
+    if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {
+        (void)hipGetLastError();
+        pool_release_all(ctx);
+        e = hipMalloc(d_ptr, size);
+    }
+    if (e != hipSuccess) return set_error((int)e, "hipMalloc(%zu bytes) failed: %s", size, hipGetErrorString(e));
+    ctx->live[*d_ptr] = size;
+    ctx->pool_misses++;
     return CHROMA_OK;
 }
 
 int chroma_free(chroma_ctx *ctx, void *d_ptr)
 {
     if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
-    if (d_ptr) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(d_ptr)); }
+    if (!d_ptr) return CHROMA_OK;
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    auto it = ctx->live.find(d_ptr);
+    if (it == ctx->live.end()) {                   // not one of ours (should not happen): the old behaviour
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(d_ptr));
+        return CHROMA_OK;
+    }
+    const size_t size = it->second;
+    ctx->live.erase(it);
+    if (ctx->pool_bytes + size > ctx->pool_limit) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(d_ptr));
+        return CHROMA_OK;
+    }
+    hipEvent_t ev;
+    if (!ctx->pool_events.empty()) { ev = ctx->pool_events.back(); ctx->pool_events.pop_back(); }
+    else HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev, ctx->stream));
+    ctx->pool.emplace(size, chroma_ctx::PoolBlock{d_ptr, ev});
+    ctx->pool_bytes += size;
+    return CHROMA_OK;
+}
+
+int chroma_pool_trim(chroma_ctx *ctx)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    pool_release_all(ctx);
+    return CHROMA_OK;
+}
+
+int chroma_pool_stats(chroma_ctx *ctx, uint64_t *parked_bytes, uint64_t *reused, uint64_t *allocated)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    if (parked_bytes) *parked_bytes = ctx->pool_bytes;
+    if (reused) *reused = ctx->pool_hits;
+    if (allocated) *allocated = ctx->pool_misses;
+    return CHROMA_OK;
+}
+
+// ---- host -> device ------------------------------------------------------------------------------------------
+// A copy from pageable host memory runs at ~11 GB/s through the runtime's own bounce buffer (one thread).  Large copies
+// are staged here instead: the host threads copy 32 MB pieces into a ring of PINNED buffers in parallel and each piece
+// goes to the device by DMA while the next is being staged.
+static int staged_htod(chroma_ctx *ctx, hipStream_t stream, void *d_dst, const void *h_src, size_t nbytes)
+{
+    std::lock_guard<std::mutex> lock(ctx->stage_mu);
+    for (int i = 0; i < chroma_ctx::STAGE_N; i++)
+        if (!ctx->stage[i]) {
+            HIP_TRY(hipHostMalloc(&ctx->stage[i], chroma_ctx::STAGE_BYTES, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+        }
+    size_t off = 0;
+    int k = 0;
+    while (off < nbytes) {
+        const size_t len = std::min(chroma_ctx::STAGE_BYTES, nbytes - off);
+        HIP_TRY(hipEventSynchronize(ctx->stage_ev[k]));            // (the DMA that last read this buffer is done)
+        char *dst = (char *)ctx->stage[k];
+        const char *src = (const char *)h_src + off;
+        chroma_host::parallel_for(len, [&](size_t a, size_t b) { memcpy(dst + a, src + a, b - a); }, 1u << 20);
+        HIP_TRY(hipMemcpyAsync((char *)d_dst + off, dst, len, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(ctx->stage_ev[k], stream));
+        off += len;
+        k = (k + 1) % chroma_ctx::STAGE_N;
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
     return CHROMA_OK;
 }
 
@@ -3123,8 +3269,24 @@ int chroma_memcpy_htod(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t n
 {
     if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
     if (nbytes == 0) return CHROMA_OK;
+    if (nbytes >= (8u << 20)) return staged_htod(ctx, ctx->stream, d_dst, h_src, nbytes);
     HIP_TRY(hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CHROMA_OK;
+}
+
+// The same copy on the context's SECOND stream: not ordered with the work queued on the main stream, so that the
+// photons of the next event batch can go up while the current batch propagates (Simulation, one thread ahead).  The
+// destination must not be in use by queued work: a block fresh from chroma_malloc never is.  Returns when the data is
+// on the device.
+int chroma_upload(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    if (nbytes == 0) return CHROMA_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (nbytes >= (8u << 20)) return staged_htod(ctx, ctx->copy_stream, d_dst, h_src, nbytes);
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
     return CHROMA_OK;
 }
 

@@ -42,8 +42,10 @@ def _vec3_to_rows(a):
 
 
 class GPUPhotons(object):
-    def __init__(self, photons, ncopies=1, copy_flags=True, copy_triangles=True, copy_weights=True):
-        """Load ``photons`` (chroma_amd.event.Photons) onto the device, ``ncopies`` times."""
+    def __init__(self, photons, ncopies=1, copy_flags=True, copy_triangles=True, copy_weights=True, upload=False):
+        """Load ``photons`` (chroma_amd.event.Photons) onto the device, ``ncopies`` times.  ``upload=True``: the
+        copies go through the context's second stream (GPUArray.set(upload=True)), so that this constructor can run in
+        another thread while a previous photon set propagates (Simulation's batch loop)."""
         self.ctx = get_context()
         nphotons = len(photons)
         n = nphotons * ncopies
@@ -62,18 +64,19 @@ class GPUPhotons(object):
         if not copy_weights:
             self.weights.fill(1.0)
 
-        self.pos[:nphotons].set(to_float3(photons.pos))
-        self.dir[:nphotons].set(to_float3(photons.dir))
-        self.pol[:nphotons].set(to_float3(photons.pol))
-        self.wavelengths[:nphotons].set(photons.wavelengths.astype(np.float32))
-        self.t[:nphotons].set(photons.t.astype(np.float32))
+        # (np.asarray: no host-side copy when the array already has the device type, as event.Photons' arrays do)
+        self.pos[:nphotons].set(to_float3(photons.pos), upload)
+        self.dir[:nphotons].set(to_float3(photons.dir), upload)
+        self.pol[:nphotons].set(to_float3(photons.pol), upload)
+        self.wavelengths[:nphotons].set(np.asarray(photons.wavelengths, dtype=np.float32), upload)
+        self.t[:nphotons].set(np.asarray(photons.t, dtype=np.float32), upload)
         if copy_triangles:
-            self.last_hit_triangles[:nphotons].set(photons.last_hit_triangles.astype(np.int32))
+            self.last_hit_triangles[:nphotons].set(np.asarray(photons.last_hit_triangles, dtype=np.int32), upload)
         if copy_flags:
-            self.flags[:nphotons].set(photons.flags.astype(np.uint32))
+            self.flags[:nphotons].set(np.asarray(photons.flags, dtype=np.uint32), upload)
         if copy_weights:
-            self.weights[:nphotons].set(photons.weights.astype(np.float32))
-        self.evidx[:nphotons].set(photons.evidx.astype(np.uint32))
+            self.weights[:nphotons].set(np.asarray(photons.weights, dtype=np.float32), upload)
+        self.evidx[:nphotons].set(np.asarray(photons.evidx, dtype=np.uint32), upload)
 
         self.true_nphotons = nphotons
         self.ncopies = ncopies

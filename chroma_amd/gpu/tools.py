@@ -112,6 +112,15 @@ class Context(object):
         """'coop' (default), 'split' or 'fused': how propagate() finishes -- or, with 'fused', runs -- a batch."""
         _lib.check(self._lib.chroma_set_tail(self.handle, {'coop': 0, 'split': 1, 'fused': 2}[mode]))
 
+    def pool_stats(self):
+        """(bytes parked in the device-memory pool, allocations served from it, allocations that went to hipMalloc)."""
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(self._lib.chroma_pool_stats(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def pool_trim(self):
+        _lib.check(self._lib.chroma_pool_trim(self.handle))
+
     def read_stats(self):
         stats = _lib.PropagateStats()
         _lib.check(self._lib.chroma_propagate_stats_read(self.handle, ctypes.byref(stats)))
@@ -204,7 +213,10 @@ class GPUArray(object):
             _lib.check(self.ctx._lib.chroma_memcpy_dtoh(self.ctx.handle, _lib.ptr(out), ctypes.c_void_p(self.ptr), self.nbytes))
         return out
 
-    def set(self, ary):
+    def set(self, ary, upload=False):
+        """Host -> device.  ``upload=True``: on the context's second stream (chroma_upload), not ordered with the work
+        queued on the main one -- for an array nothing queued is using, e.g. one just allocated (Simulation's
+        prefetching batch loop)."""
         ary = np.ascontiguousarray(ary)
         if ary.dtype != self.dtype:
             if ary.dtype.itemsize * ary.size == self.nbytes and (ary.dtype.fields or self.dtype.fields):
@@ -214,7 +226,8 @@ class GPUArray(object):
         if ary.size != self.size:
             raise ValueError('size mismatch: %d vs %d' % (ary.size, self.size))
         if self.size:
-            _lib.check(self.ctx._lib.chroma_memcpy_htod(self.ctx.handle, ctypes.c_void_p(self.ptr), _lib.ptr(ary), self.nbytes))
+            copy = self.ctx._lib.chroma_upload if upload else self.ctx._lib.chroma_memcpy_htod
+            _lib.check(copy(self.ctx.handle, ctypes.c_void_p(self.ptr), _lib.ptr(ary), self.nbytes))
         return self
 
     def fill(self, value):

@@ -21,10 +21,15 @@ def pick_seed():
 
 class Simulation(object):
     def __init__(self, detector, seed=None, cuda_device=None, particle_tracking=False, photon_tracking=False,
-                 geant4_processes=0, nthreads_per_block=64, max_blocks=1024, exact=False):
+                 geant4_processes=0, nthreads_per_block=64, max_blocks=1024, exact=False, prefetch=True):
         # ``exact``: propagate with the reference's own traversal loop for every ray (GPUPhotons.propagate(exact=True)):
         # the reference's hit triangle on every ray, several times slower than the default walk
         self.exact = bool(exact)
+        # ``prefetch``: simulate() uploads the photons of the NEXT batch (another host thread, the context's second
+        # stream, pinned staging buffers) while the current batch propagates; the batches' device arrays come from the
+        # library's pool, so after the first two batches nothing is allocated.  The user's iterable is read one batch
+        # ahead of the events that are yielded.
+        self.prefetch = bool(prefetch)
         self.detector = detector
         self.nthreads_per_block = nthreads_per_block
         self.max_blocks = max_blocks
@@ -46,15 +51,24 @@ class Simulation(object):
         self.rng_states = gpu.get_rng_states(self.nthreads_per_block * self.max_blocks, seed=self.seed)
         self.pdf_config = None
 
-    def _simulate_batch(self, batch_events, keep_photons_beg=False, keep_photons_end=False, keep_hits=True,
-                        keep_flat_hits=True, run_daq=False, max_steps=100, verbose=False):
-        """Propagate the photons of all ``batch_events`` in one go and split the results
-        back per event (by evidx).  Yields the events."""
-        t_start = timer()
-        batch_photons = event.Photons.join([ev.photons_beg for ev in batch_events])
+    def _upload_batch(self, batch_events, upload=True):
+        """The photons of all ``batch_events`` as one GPUPhotons (chroma/sim.py:66-72) + the events' bounds in it.
+        With ``upload`` the copies use the context's second stream: safe to run while another batch propagates."""
+        if len(batch_events) == 1:
+            batch_photons = batch_events[0].photons_beg                  # (no host-side concatenation)
+        else:
+            batch_photons = event.Photons.join([ev.photons_beg for ev in batch_events])
         bounds = np.cumsum(np.concatenate([[0], [len(ev.photons_beg) for ev in batch_events]]))
+        return gpu.GPUPhotons(batch_photons, copy_triangles=False, copy_weights=False, upload=upload), bounds
 
-        gpu_photons = gpu.GPUPhotons(batch_photons, copy_triangles=False, copy_weights=False)
+    def _simulate_batch(self, batch_events, keep_photons_beg=False, keep_photons_end=False, keep_hits=True,
+                        keep_flat_hits=True, run_daq=False, max_steps=100, verbose=False, uploaded=None):
+        """Propagate the photons of all ``batch_events`` in one go and split the results
+        back per event (by evidx).  Yields the events.  ``uploaded``: what _upload_batch returned for them."""
+        t_start = timer()
+        if uploaded is None:
+            uploaded = self._upload_batch(batch_events, upload=False)
+        gpu_photons, bounds = uploaded
         t_copy = timer()
         tracking = gpu_photons.propagate(self.gpu_geometry, self.rng_states,
                                          nthreads_per_block=self.nthreads_per_block, max_blocks=self.max_blocks,
@@ -118,22 +132,42 @@ class Simulation(object):
 
         kwargs = dict(keep_photons_beg=keep_photons_beg, keep_photons_end=keep_photons_end, keep_hits=keep_hits,
                       keep_flat_hits=keep_flat_hits, run_daq=run_daq, max_steps=max_steps)
-        nphotons = 0
-        batch = []
-        evid = evid_start
-        for ev in iterable:
-            ev.id = evid
-            evid += 1
-            ev.nphotons = len(ev.photons_beg)
-            ev.photons_beg.evidx[:] = len(batch)
-            nphotons += ev.nphotons
-            batch.append(ev)
-            if nphotons >= photons_per_batch:
+        def batches():
+            nphotons = 0
+            batch = []
+            evid = evid_start
+            for ev in iterable:
+                ev.id = evid
+                evid += 1
+                ev.nphotons = len(ev.photons_beg)
+                ev.photons_beg.evidx[:] = len(batch)
+                nphotons += ev.nphotons
+                batch.append(ev)
+                if nphotons >= photons_per_batch:
+                    yield batch
+                    nphotons = 0
+                    batch = []
+            if batch:
+                yield batch
+
+        if not self.prefetch or self.photon_tracking:
+            for batch in batches():
                 yield from self._simulate_batch(batch, **kwargs)
-                nphotons = 0
-                batch = []
-        if batch:
-            yield from self._simulate_batch(batch, **kwargs)
+            return
+        # one batch ahead: while batch k propagates (the library call releases the GIL), a second thread stages and
+        # uploads batch k + 1 on the context's second stream
+        from concurrent.futures import ThreadPoolExecutor
+        it = batches()
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            cur = next(it, None)
+            fut = pool.submit(self._upload_batch, cur) if cur is not None else None
+            while cur is not None:
+                uploaded = fut.result()
+                nxt = next(it, None)
+                fut = pool.submit(self._upload_batch, nxt) if nxt is not None else None
+                yield from self._simulate_batch(cur, uploaded=uploaded, **kwargs)
+                uploaded = None
+                cur = nxt
 
     def __del__(self):
         try:

@@ -182,7 +182,20 @@ int chroma_device_name(chroma_ctx *ctx, char *buf, size_t buflen);
 /* ---- device memory: replaces pycuda.gpuarray allocation / get / set ---- */
 int chroma_malloc(chroma_ctx *ctx, size_t nbytes, void **d_ptr);
 int chroma_free(chroma_ctx *ctx, void *d_ptr);
+/* (chroma_free parks the block in a pool and chroma_malloc reuses a parked block of the same size once the work that
+ *  was queued when it was freed has completed: a GPUPhotons per event batch costs no hipMalloc / hipFree after the
+ *  first.  chroma_pool_trim gives everything parked back to the device; chroma_pool_stats: bytes parked, allocations
+ *  served from the pool, allocations that went to hipMalloc.) */
+int chroma_pool_trim(chroma_ctx *ctx);
+int chroma_pool_stats(chroma_ctx *ctx, uint64_t *parked_bytes, uint64_t *reused, uint64_t *allocated);
+/* (copies of 8 MB and more are staged through pinned buffers by all host threads, piece by piece, DMA overlapping the
+ *  staging of the next piece.)  Synchronous: ordered after the work queued on the context's stream. */
 int chroma_memcpy_htod(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes);
+/* The same on the context's second stream -- NOT ordered with the queued work, so that the next event batch can be
+ * uploaded (by another host thread) while the current one propagates: replaces the copies of GPUPhotons.__init__
+ * (chroma/gpu/photon.py:13-94) in Simulation's batch loop (chroma/sim.py:58-139).  d_dst must not be in use by queued
+ * work (a block fresh from chroma_malloc is not).  Returns when the data is on the device. */
+int chroma_upload(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes);
 int chroma_memcpy_dtoh(chroma_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes);
 int chroma_memcpy_dtod(chroma_ctx *ctx, void *d_dst, const void *d_src, size_t nbytes);
 int chroma_memset32(chroma_ctx *ctx, void *d_dst, uint32_t value, size_t count);

@@ -13,8 +13,9 @@ from chroma_amd.gpu.geometry import pack_geometry
 config = sys.argv[1] if len(sys.argv) > 1 else 'c3'
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 50_000_000
 geo = create_geometry_from_obj({'tiny': demo.tiny, 'lite': demo.detector_lite, 'detector': demo.detector, 'c3': demo.detector29k}[config]())
-ctx = gpu.create_cuda_context(0)
-gg = gpu.GPUDetector(geo, packed=pack_geometry(geo))
+from chroma_amd.sim import Simulation
+sim0 = Simulation(geo, seed=5, prefetch=False)          # (creates the context and uploads the geometry once)
+ctx, gg = sim0.context, sim0.gpu_geometry
 rng = np.random.default_rng(1)
 d = rng.standard_normal((n, 3), dtype=np.float32); d /= np.linalg.norm(d, axis=1)[:, None]
 pol = np.cross(d, np.roll(d, 1, axis=1)).astype(np.float32); pol /= np.linalg.norm(pol, axis=1)[:, None]
@@ -32,3 +33,16 @@ for rep in range(3):
           'end to end, %.3g with resident inputs' % (config, n, t1 - t0, n * 64e-9 / (t1 - t0), t2 - t1, len(hits), t3 - t2,
                                                      n / (t3 - t0), n / (t3 - t1)), flush=True)
     del gp, hits
+
+# the whole batch loop of Simulation (chroma/sim.py:58-139): several batches of host photons, hits back to the host,
+# with and without the prefetching upload (second thread + second stream + pooled device arrays)
+nb = 4
+for prefetch in (False, True):
+    sim = sim0
+    sim.prefetch = prefetch
+    list(sim.simulate([host], keep_hits=False, photons_per_batch=n, max_steps=100))            # warm-up: pool, staging buffers
+    t0 = time.perf_counter()
+    nhits = sum(len(ev.flat_hits) for ev in sim.simulate([host] * nb, keep_hits=False, photons_per_batch=n, max_steps=100))
+    dt = time.perf_counter() - t0
+    print('Simulation.simulate, %d batches of %d host photons, prefetch=%s: %.3f s -> %.3g photons/s end to end (%d flat hits on the host)' % (
+        nb, n, prefetch, dt, nb * n / dt, nhits), flush=True)
