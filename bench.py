@@ -16,6 +16,7 @@ stream keyed by the GLOBAL photon id) and the per-GPU work is fixed (weak scalin
 shard is 1.25e8 photons (BASELINE.json configs[3]: 1e9 photons over 8 GPUs).  Rank 0 prints ONE JSON line.
 """
 import argparse
+from ctypes import c_uint32 as ctypes_uint32
 import hashlib
 import json
 import os
@@ -74,6 +75,18 @@ def geometry_source_hash():
         except OSError:
             pass
     return h.hexdigest()[:12]
+
+
+def gg_plain(gg):
+    """True when the geometry's optics are plain (the k_physics<false> build runs)."""
+    try:
+        d = gg.packed.desc
+        import numpy as np
+        models = np.ctypeslib.as_array((ctypes_uint32 * int(d.nsurfaces)).from_address(d.surf_model)) if d.nsurfaces and d.surf_model else []
+        comps = np.ctypeslib.as_array((ctypes_uint32 * int(d.nmaterials)).from_address(d.mat_num_comp)) if d.nmaterials and d.mat_num_comp else []
+        return not (any(int(m) != 0 for m in models) or any(int(c) != 0 for c in comps)) and not os.environ.get('CHROMA_FULL_PHYSICS')
+    except Exception:
+        return True
 
 
 def effective_cores():
@@ -384,9 +397,17 @@ def main():
     # quoted only when that profile was taken with the kernels this run was built from
     traffic, traffic_source, measured = None, 'none: no PMC profile of this command under profiles/', None
     src_hash = kernel_source_hash()
+    sq, physics_traffic, physics_sq = None, None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
         key = '%s:%d:%d' % (args.config, nphotons, args.max_steps)
+        # issue-side counters and the second kernel's traffic: quoted under the same rule (this build's hash only)
+        if pmc.get(key + ':sq', {}).get('source_hash') == src_hash:
+            sq = pmc[key + ':sq']
+        if pmc.get(key + ':physics', {}).get('source_hash') == src_hash:
+            physics_traffic = pmc[key + ':physics']
+        if pmc.get(key + ':physics:sq', {}).get('source_hash') == src_hash:
+            physics_sq = pmc[key + ':physics:sq']
         if key in pmc:
             rec = pmc[key]
             if rec.get('source_hash') == src_hash:
@@ -415,6 +436,27 @@ def main():
             ctx.set_walk('quad')
         log('exact (literal reference) walk: %.3g photons/s on one batch (%.1fx slower than the default walk)' % (
             exact_rate, (value / world) / exact_rate))
+
+    # the second kernel of a step, k_physics (main pass): per photon step it reads the hit entry (8 B), the photon's
+    # record (64 B) and the winning triangle's record (48 B), writes a survivor's record, next ray and queue slot
+    # (64 + 64 + 4 B) or a finished photon's ten array entries (64 B); every photon ends exactly once
+    phys_s = stats.get('physics_ms', 0.0) / 1e3
+    phys_bytes_per_step = 120.0 + 132.0 * (1.0 - 1.0 / steps_pp) + 64.0 / steps_pp
+    phys_bytes_total = phys_bytes_per_step * steps_pp * nphotons * args.steps
+    phys_launches = max(1, stats.get('physics_launches', 0))
+    physics = {'kernel': 'k_physics<%s>' % ('false' if gg_plain(gg) else 'true'), 'kernel_s': phys_s, 'launches': int(stats.get('physics_launches', 0)),
+               'ms_per_batch': 1e3 * phys_s / args.steps,
+               'algorithmic_bytes_per_photon_step': phys_bytes_per_step,
+               'algorithmic_GBps': phys_bytes_total / phys_s / 1e9 if phys_s > 0 else None,
+               'algorithmic_frac': phys_bytes_total / phys_s / 1e9 / HBM_PEAK_GBS if phys_s > 0 else None,
+               'hbm_measured_GBps': None, 'traffic_over_algorithmic': None,
+               'valu_lane_utilisation': physics_sq['valu_lane_utilisation'] if physics_sq else None,
+               'wait_frac': physics_sq['wait_frac'] if physics_sq else None}
+    if physics_traffic and phys_s > 0:
+        # (the PMC figure is per launch over main AND fix-up launches, which come in pairs: two launches per step)
+        per_step = 2.0 * physics_traffic['hbm_bytes_per_launch']
+        physics['hbm_measured_GBps'] = per_step * stats.get('physics_launches', 0) / phys_s / 1e9
+        physics['traffic_over_algorithmic'] = per_step * stats.get('physics_launches', 0) / phys_bytes_total
 
     cpu_baseline = None
     if run_cpu:
@@ -491,7 +533,13 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': RAYCAST_KERNEL, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'hbm_measured_GBps': measured, 'hbm_measured_frac': (measured / HBM_PEAK_GBS) if measured else None,
-                         'limiter': 'VALU issue (PMC, profiles/r02/pmc_quad_final.txt: SQ_ACTIVE_INST_VALU x 4 = 98 % of the SIMD cycles of the launches), not bandwidth',
+                         'limiter': 'VALU issue, not bandwidth: SQ_ACTIVE_INST_VALU x 4 = %s of the SIMD cycles of the launches' % (
+                             ('%.0f %% (PMC pass of this build, profiles/pmc_traffic.json)' % (100 * sq['valu_issue_frac'])) if sq else
+                             '98 % in the last counter pass (profiles/r02/pmc_quad_final.txt; no SQ pass of this build yet)'),
+                         'valu_issue_frac': sq['valu_issue_frac'] if sq else None,
+                         'valu_lane_utilisation': sq['valu_lane_utilisation'] if sq else None,
+                         'salu_per_valu': sq['salu_per_valu'] if sq else None,
+                         'physics': physics,
                          'algorithmic_bytes_per_launch': ray_bytes_total / ray_launches,
                          'algorithmic_bytes_per_photon_step': ray_bytes_per_step,
                          'launches': int(stats['raycast_launches']), 'avg_launch_ms': avg_launch_ms,

@@ -70,7 +70,8 @@ class PropagateStats(Structure):
     """chroma_propagate_stats"""
     _fields_ = [('photon_steps', c_uint64), ('nodes_visited', c_uint64), ('triangles_tested', c_uint64),
                 ('launches', c_uint64), ('stack_overflows', c_uint64), ('kernel_ms', c_double),
-                ('raycast_ms', c_double), ('raycast_launches', c_uint64), ('stack_spills', c_uint64)]
+                ('raycast_ms', c_double), ('raycast_launches', c_uint64), ('stack_spills', c_uint64),
+                ('physics_ms', c_double), ('physics_launches', c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

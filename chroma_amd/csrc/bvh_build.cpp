@@ -74,7 +74,7 @@ size_t count_unique_sorted_shifted(const std::vector<uint64_t> &m, int shift)
     size_t n = m.size();
     if (n == 0) return 0;
     std::vector<size_t> partial(64, 0);
-    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    unsigned nt = std::max(1u, std::min(chroma_host::hw_threads(), 32u));
     if (n < (1u << 16)) nt = 1;
     std::vector<std::thread> th;
     size_t chunk = (n + nt - 1) / nt;

@@ -121,7 +121,7 @@ struct chroma_ctx {
     hipStream_t copy_stream = nullptr;
     std::mutex stage_mu;
     static constexpr int STAGE_N = 3;
-    static constexpr size_t STAGE_BYTES = 32u << 20;
+    static constexpr size_t STAGE_BYTES = 64u << 20;
     void *stage[STAGE_N] = {nullptr, nullptr, nullptr};
     hipEvent_t stage_ev[STAGE_N] = {nullptr, nullptr, nullptr};
 };
@@ -2694,8 +2694,8 @@ static size_t spill_entries(const chroma_ctx *ctx)
 // One step as ray set-up + ray cast + physics (+ the strict walk and the physics of the few rays that
 // need it), all reading the photon count and the launch policy from ctx->d_step (k_step_begin).
 // `n_upper` bounds the count and sizes the grids; `in_q`/`out_q` are whole queues (slot 0 = tail) and
-// `work_in`/`work_out` the working sets that go with them.  With `ev` (4 events): [0] step start,
-// [3] ray-cast kernel start, [1] its end, [2] step end.
+// `work_in`/`work_out` the working sets that go with them.  With `ev` (5 events): [0] step start,
+// [3] ray-cast kernel start, [1] its end, [4] end of the main physics pass, [2] step end.
 // The walk whose steps chain their ray records from kernel to kernel (k_load_working -> k_raycast_quad -> k_physics ->
 // k_raycast_quad ...) instead of running k_ray_setup: the default one.
 static bool step_uses_quad_walk(const chroma_ctx *ctx, const chroma_geometry *geom)
@@ -2744,7 +2744,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
             hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                                ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
                                ctx->retry_list, 2, pc, (float4 *)nullptr);
-        if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+        if (ev) { HIP_TRY(hipEventRecord(ev[4], ctx->stream)); HIP_TRY(hipEventRecord(ev[2], ctx->stream)); }
         HIP_TRY(hipGetLastError());
         return CHROMA_OK;
     }
@@ -2817,6 +2817,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
         hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                            ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
                            ctx->retry_list, 0, pc, rays_next);
+    if (ev) HIP_TRY(hipEventRecord(ev[4], ctx->stream));          // end of the main physics pass
     // (both passes stride over the list and leave at once when it is short -- the usual case -- but a plain geometry
     //  with faces on the world box lists a good part of its hits for the exact check: grids for that)
     const unsigned rblocks = (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK, 8 * 256);
@@ -3238,8 +3239,9 @@ int chroma_pool_stats(chroma_ctx *ctx, uint64_t *parked_bytes, uint64_t *reused,
 
 // ---- host -> device ------------------------------------------------------------------------------------------
 // A copy from pageable host memory runs at ~11 GB/s through the runtime's own bounce buffer (one thread).  Large copies
-// are staged here instead: the host threads copy 32 MB pieces into a ring of PINNED buffers in parallel and each piece
-// goes to the device by DMA while the next is being staged.
+// are staged here instead: the host threads copy 64 MB pieces into a ring of PINNED buffers in parallel and each piece
+// goes to the device by DMA while the next is being staged.  (r03: 11.2 -> 16 GB/s with 32 MB pieces and 64 threads on
+// a 16-core quota; the thread count now follows the quota.)
 static int staged_htod(chroma_ctx *ctx, hipStream_t stream, void *d_dst, const void *h_src, size_t nbytes)
 {
     std::lock_guard<std::mutex> lock(ctx->stage_mu);
@@ -3860,8 +3862,8 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     uint32_t *in_q = ctx->queue_a, *out_q = ctx->queue_b;
     float4 *work_in = ctx->work_a, *work_out = ctx->work_b;
 
-    double kernel_ms = 0.0, raycast_ms = 0.0;
-    uint64_t launches = 0, raycast_launches = 0;
+    double kernel_ms = 0.0, raycast_ms = 0.0, physics_ms = 0.0;
+    uint64_t launches = 0, raycast_launches = 0, physics_launches = 0;
     // Launch policy of the reference (chroma/gpu/photon.py:225-252): one step per launch while many
     // photons are alive, and ONE launch for all remaining steps once fewer than 64*16*8 are left (or
     // with weights).  A launch re-normalises dir/pol when it loads a photon (propagate.cu:248,250), so
@@ -3883,7 +3885,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                                step_uses_quad_walk(ctx, geom) ? ctx->rays : nullptr);
         }
         HIP_TRY(hipGetLastError());
-        const int nev = time_kernels ? 4 * max_steps : 0;
+        const int nev = time_kernels ? 5 * max_steps : 0;
         while ((int)ctx->step_events.size() < nev) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->step_events.push_back(e); }
         long long n_upper = (long long)nphotons;
         int step = 0, next_check = 1, steps_timed = 0;
@@ -3897,7 +3899,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                 // the reference's last launch: all remaining steps at once, 8 lanes per photon
                 bool launched = false;
                 rc = launch_tail(ctx, geom, pv, n_upper, in_q, out_q, work_in, rng, max_steps - step, use_weights,
-                                 step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 4 * step : nullptr, &launched,
+                                 step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 5 * step : nullptr, &launched,
                                  step == 0 ? (uint32_t)nphotons : 0u);
                 if (rc) return rc;
                 if (launched) {
@@ -3908,7 +3910,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                 }
             }
             rc = launch_split_step(ctx, geom, pv, n_upper, in_q, out_q, work_in, work_out, rng, use_weights,
-                                   step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 4 * step : nullptr,
+                                   step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 5 * step : nullptr,
                                    step == 0 ? (uint32_t)nphotons : 0u, step_uses_quad_walk(ctx, geom));
             if (rc) return rc;
             if (time_kernels) steps_timed = step + 1;
@@ -3935,12 +3937,15 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         launches = ((const StepState *)ctx->h_step)->launches;
         for (int k = 0; k < steps_timed; k++) {
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[4 * k], ctx->step_events[4 * k + 2]));
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[5 * k], ctx->step_events[5 * k + 2]));
             kernel_ms += ms;
             if (k == tail_step) continue;             // the fused tail is not a ray-cast launch
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[4 * k + 3], ctx->step_events[4 * k + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[5 * k + 3], ctx->step_events[5 * k + 1]));
             raycast_ms += ms;
             raycast_launches++;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[5 * k + 1], ctx->step_events[5 * k + 4]));
+            physics_ms += ms;                         // the main pass of k_physics (not the fix-up pass)
+            physics_launches++;
         }
     } else {
         // CHROMA_TAIL=fused: the lane-per-photon kernel with the reference's own launch shapes
@@ -3994,6 +3999,8 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         stats->kernel_ms += kernel_ms;
         stats->raycast_ms += raycast_ms;
         stats->raycast_launches += raycast_launches;
+        stats->physics_ms += physics_ms;
+        stats->physics_launches += physics_launches;
         if (stats->stack_overflows) return set_error(CHROMA_ERR_STACK, "traversal stack overflowed for %llu rays", (unsigned long long)stats->stack_overflows);
     } else {
         chroma_propagate_stats tmp; memset(&tmp, 0, sizeof tmp);

@@ -3,6 +3,10 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <stdio.h>
+#ifdef __linux__
+#include <sched.h>
+#endif
 #include <algorithm>
 #include <thread>
 #include <vector>
@@ -11,10 +15,32 @@ namespace chroma_host {
 
 // threads of the host-side builders: the machine's, at most 64, or CHROMA_HOST_THREADS (several
 // processes building the same geometry on one node, one per GPU, share the cores)
+// (the cores this process may really use: its affinity mask, capped by the cgroup's CPU quota -- a container that shows
+//  256 logical CPUs with a quota of 16 must not get 64 threads per parallel loop)
+inline unsigned usable_cores()
+{
+    static const unsigned cached = [] {
+        unsigned n = std::thread::hardware_concurrency();
+#ifdef __linux__
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { int c = CPU_COUNT(&set); if (c > 0) n = (unsigned)c; }
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char quota[64]; double period = 0.0;
+            if (fscanf(f, "%63s %lf", quota, &period) == 2 && quota[0] != 'm' && period > 0.0) {
+                double q = atof(quota) / period;
+                if (q >= 1.0) n = std::min<unsigned>(n, (unsigned)(q + 0.5));
+            }
+            fclose(f);
+        }
+#endif
+        return std::max(1u, n);
+    }();
+    return cached;
+}
+
 inline unsigned hw_threads()
 {
-    unsigned n = std::thread::hardware_concurrency();
-    n = std::max(1u, std::min(n ? n : 1u, 64u));
+    unsigned n = std::max(1u, std::min(usable_cores(), 64u));
     if (const char *e = getenv("CHROMA_HOST_THREADS")) { int v = atoi(e); if (v > 0) n = std::min<unsigned>((unsigned)v, 64u); }
     return n;
 }

@@ -47,7 +47,10 @@ class GPUPhotons(object):
         copies go through the context's second stream (GPUArray.set(upload=True)), so that this constructor can run in
         another thread while a previous photon set propagates (Simulation's batch loop)."""
         self.ctx = get_context()
-        nphotons = len(photons)
+        # ``photons`` may also be a LIST of Photons objects (the events of a batch): each is copied straight into its
+        # slice of the device arrays, without concatenating them on the host first
+        parts = list(photons) if isinstance(photons, (list, tuple)) else [photons]
+        nphotons = sum(len(p) for p in parts)
         n = nphotons * ncopies
         f = _alloc_fields(n, self.ctx)
         self.pos, self.dir, self.pol = f['pos'], f['dir'], f['pol']
@@ -65,18 +68,23 @@ class GPUPhotons(object):
             self.weights.fill(1.0)
 
         # (np.asarray: no host-side copy when the array already has the device type, as event.Photons' arrays do)
-        self.pos[:nphotons].set(to_float3(photons.pos), upload)
-        self.dir[:nphotons].set(to_float3(photons.dir), upload)
-        self.pol[:nphotons].set(to_float3(photons.pol), upload)
-        self.wavelengths[:nphotons].set(np.asarray(photons.wavelengths, dtype=np.float32), upload)
-        self.t[:nphotons].set(np.asarray(photons.t, dtype=np.float32), upload)
-        if copy_triangles:
-            self.last_hit_triangles[:nphotons].set(np.asarray(photons.last_hit_triangles, dtype=np.int32), upload)
-        if copy_flags:
-            self.flags[:nphotons].set(np.asarray(photons.flags, dtype=np.uint32), upload)
-        if copy_weights:
-            self.weights[:nphotons].set(np.asarray(photons.weights, dtype=np.float32), upload)
-        self.evidx[:nphotons].set(np.asarray(photons.evidx, dtype=np.uint32), upload)
+        lo = 0
+        for part in parts:
+            hi = lo + len(part)
+            if hi > lo:
+                self.pos[lo:hi].set(to_float3(part.pos), upload)
+                self.dir[lo:hi].set(to_float3(part.dir), upload)
+                self.pol[lo:hi].set(to_float3(part.pol), upload)
+                self.wavelengths[lo:hi].set(np.asarray(part.wavelengths, dtype=np.float32), upload)
+                self.t[lo:hi].set(np.asarray(part.t, dtype=np.float32), upload)
+                if copy_triangles:
+                    self.last_hit_triangles[lo:hi].set(np.asarray(part.last_hit_triangles, dtype=np.int32), upload)
+                if copy_flags:
+                    self.flags[lo:hi].set(np.asarray(part.flags, dtype=np.uint32), upload)
+                if copy_weights:
+                    self.weights[lo:hi].set(np.asarray(part.weights, dtype=np.float32), upload)
+                self.evidx[lo:hi].set(np.asarray(part.evidx, dtype=np.uint32), upload)
+            lo = hi
 
         self.true_nphotons = nphotons
         self.ncopies = ncopies

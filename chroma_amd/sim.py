@@ -54,8 +54,11 @@ class Simulation(object):
     def _upload_batch(self, batch_events, upload=True):
         """The photons of all ``batch_events`` as one GPUPhotons (chroma/sim.py:66-72) + the events' bounds in it.
         With ``upload`` the copies use the context's second stream: safe to run while another batch propagates."""
-        if len(batch_events) == 1:
-            batch_photons = batch_events[0].photons_beg                  # (no host-side concatenation)
+        # (large events go to their slice of the device arrays directly; many small ones are joined on the host first:
+        #  a copy call per array per event would cost more than the concatenation)
+        sizes = [len(ev.photons_beg) for ev in batch_events]
+        if len(batch_events) == 1 or min(sizes) >= 1_000_000:
+            batch_photons = [ev.photons_beg for ev in batch_events]
         else:
             batch_photons = event.Photons.join([ev.photons_beg for ev in batch_events])
         bounds = np.cumsum(np.concatenate([[0], [len(ev.photons_beg) for ev in batch_events]]))

@@ -166,6 +166,8 @@ typedef struct chroma_propagate_stats {
     uint64_t raycast_launches;   /* number of ray-cast launches timed in raycast_ms              */
     uint64_t stack_spills;       /* stack entries pushed beyond the LDS part of a fast walk's stack
                                     (counting mode only; the deep-stack path of the 4- and 8-lane walks) */
+    double   physics_ms;         /* HIP-event time of the main k_physics pass of every timed step            */
+    uint64_t physics_launches;
 } chroma_propagate_stats;
 
 const char *chroma_last_error(void);

@@ -75,7 +75,7 @@ def test_simulation_with_prefetch_equals_simulation_without(gpu, tiny_geometry, 
         results[prefetch] = out
         if prefetch:
             parked, reused, allocated = ctx.pool_stats()
-            assert reused > allocated          # (five batches: two sets of ten arrays allocated, the rest reused)
+            assert reused >= 30                # (five batches of ten arrays: two sets allocated at most, the rest come from the pool)
     assert [r[0] for r in results[False]] == list(range(10)) == [r[0] for r in results[True]]
     for (ida, enda, hitsa), (idb, endb, hitsb) in zip(results[False], results[True]):
         assert_bit_exact(enda, endb, 'event %d with and without prefetch' % ida)

@@ -17,12 +17,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_c3 -- pytho
 python tools/prof_summary.py $out/rocprof_c3 $out/rocprof_c3_default_summary.txt bench.py
 rm -rf $out/rocprof_c3
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 300 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $out/pmc_$c.stdout 2> $out/pmc_$c.stderr || exit 1
+  timeout -k 5 300 CHROMA_BENCH_NO_EXACT=1 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $out/pmc_$c.stdout 2> $out/pmc_$c.stderr || exit 1
 done
 python tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE c3:100000000:100 > $out/pmc_traffic.txt
 python tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE c3:100000000:100:physics k_physics >> $out/pmc_traffic.txt
 cat $out/pmc_traffic.txt
 rm -rf $out/pmc_FETCH_SIZE/*/*agent_info.csv
+# issue-side counters (SQ groups 1 and 2 of tools/pmc.sh) of the same command, into the same JSON under the same hash
+PMC_GROUPS="1 2" PMC_TIMEOUT=300 tools/pmc.sh $out/pmc_sq python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $out/pmc_sq.txt 2>&1
+python tools/pmc_sq.py $out/pmc_sq c3:100000000:100 >> $out/pmc_traffic.txt
+rm -rf $out/pmc_sq/pass*/*/*agent_info.csv
 python bench.py --no-cpu-baseline > $out/bench_c3_with_traffic.json 2> $out/bench_c3_with_traffic.log
 rm -rf /dev/shm/chroma_geo_cache
 cat $out/bench_*.json
