@@ -83,6 +83,7 @@ struct chroma_ctx {
     float4 *rays = nullptr;                // [capacity][4] ray records (k_ray_setup / k_load_working / k_physics)
     float4 *rays_b = nullptr;              // the records of the NEXT step while k_physics writes them (default walk)
     float4 *work_a = nullptr, *work_b = nullptr;    // [capacity][4] the dense working sets that go with queue_a / queue_b
+    float4 *final_rec = nullptr; uint32_t final_epoch = 0;      // (PHYS_ENDED_AOS experiment)
     // small device scratch: [0..3] DeviceCounters, then misc words
     DeviceCounters *d_counters = nullptr;
     uint32_t *d_words = nullptr;        // 16 words
@@ -1895,11 +1896,15 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
 #define PHYS_PLAIN_BLOCK 256        // -2 ms per C3 step against 512 threads at 4 waves (profiles/r03/ab_physics_occupancy.txt)
 #endif
 #define PHYS_BLOCK_OF(FULL) ((FULL) ? PHYS_BLOCK : PHYS_PLAIN_BLOCK)
+#ifndef PHYS_ENDED_AOS
+#define PHYS_ENDED_AOS 0     // experiment (profiles/r03/ab_physics_ended_aos.txt): a photon that ends in k_physics goes as ONE 64-byte
+#endif                       // record to final[photon id] and a streaming kernel fills the caller's ten arrays at the end of the call
 template <bool FULL>
 __global__ __launch_bounds__(PHYS_BLOCK_OF(FULL)) __attribute__((amdgpu_waves_per_eu(FULL ? PHYS_WAVES_PER_EU : PHYS_PLAIN_WAVES_PER_EU))) void
 k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32_t *output_queue, float4 *work_out,
           const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base,
-          int use_weights, int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters, float4 *rays_next)
+          int use_weights, int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters, float4 *rays_next,
+          float4 *final_rec = nullptr, uint32_t epoch = 0u)
 {
     // Two passes per step.  Main pass (fixup = 0): every slot of the working set; a slot the ray cast
     // handed to the strict walk (HIT_RETRY) is left alone, and so is a hit that is not REGULAR
@@ -2022,6 +2027,13 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
             counter = rng.counter;
             alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
             if (!alive) {
+#if PHYS_ENDED_AOS
+                float4 *f = final_rec + 4 * (size_t)photon_id;
+                f[0] = make_float4(p.position.x, p.position.y, p.position.z, p.wavelength);
+                f[1] = make_float4(p.direction.x, p.direction.y, p.direction.z, p.time);
+                f[2] = make_float4(p.polarization.x, p.polarization.y, p.polarization.z, p.weight);
+                f[3] = make_float4(__uint_as_float(p.history), __uint_as_float(counter), __int_as_float(p.last_hit_triangle), __uint_as_float(epoch));
+#else
                 pv.rng_counters[photon_id] = counter;
                 store3(pv.pos, photon_id, p.position);
                 store3(pv.dir, photon_id, p.direction);
@@ -2031,6 +2043,7 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
                 pv.flags[photon_id] = p.history;
                 pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
                 pv.weights[photon_id] = p.weight;
+#endif
             }
         }
     }
@@ -2112,6 +2125,28 @@ __global__ void k_store_working(GeoView g, PhotonView pv, const uint32_t *queue,
         pv.last_hit_triangles[photon_id] = rec >= 0 ? (int)g.dev_to_tri[rec] : -1;
     }
 }
+
+#if PHYS_ENDED_AOS
+// the photons that ended in k_physics during this call (their record carries the call's epoch): to the caller's arrays
+__global__ __launch_bounds__(256) void k_store_final(PhotonView pv, const float4 *final_rec, uint64_t n, uint32_t epoch)
+{
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (uint64_t)gridDim.x * blockDim.x) {
+        const float4 *f = final_rec + 4 * id;
+        const float4 f3 = f[3];
+        if (__float_as_uint(f3.w) != epoch) continue;
+        const float4 f0 = f[0], f1 = f[1], f2 = f[2];
+        store3(pv.pos, id, mk3(f0.x, f0.y, f0.z));
+        store3(pv.dir, id, mk3(f1.x, f1.y, f1.z));
+        store3(pv.pol, id, mk3(f2.x, f2.y, f2.z));
+        pv.wavelengths[id] = f0.w;
+        pv.t[id] = f1.w;
+        pv.weights[id] = f2.w;
+        pv.flags[id] = __float_as_uint(f3.x);
+        pv.rng_counters[id] = __float_as_uint(f3.y);
+        pv.last_hit_triangles[id] = __float_as_int(f3.z);
+    }
+}
+#endif
 
 // initial queue of GPUPhotons.propagate (chroma/gpu/photon.py:206-216): slot 0 unused counter,
 // then photon ids with the ncopies clones of a photon next to each other.
@@ -2739,11 +2774,11 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
         if (geom->view.plain_optics != 0)
             hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK_OF(false)), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                                ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                               ctx->retry_list, 2, pc, (float4 *)nullptr);
+                               ctx->retry_list, 2, pc, (float4 *)nullptr, ctx->final_rec, ctx->final_epoch);
         else
             hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                                ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                               ctx->retry_list, 2, pc, (float4 *)nullptr);
+                               ctx->retry_list, 2, pc, (float4 *)nullptr, ctx->final_rec, ctx->final_epoch);
         if (ev) { HIP_TRY(hipEventRecord(ev[4], ctx->stream)); HIP_TRY(hipEventRecord(ev[2], ctx->stream)); }
         HIP_TRY(hipGetLastError());
         return CHROMA_OK;
@@ -2812,11 +2847,11 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (plain)
         hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK_OF(false)), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                            ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                           ctx->retry_list, 0, pc, rays_next);
+                           ctx->retry_list, 0, pc, rays_next, ctx->final_rec, ctx->final_epoch);
     else
         hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                            ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                           ctx->retry_list, 0, pc, rays_next);
+                           ctx->retry_list, 0, pc, rays_next, ctx->final_rec, ctx->final_epoch);
     if (ev) HIP_TRY(hipEventRecord(ev[4], ctx->stream));          // end of the main physics pass
     // (both passes stride over the list and leave at once when it is short -- the usual case -- but a plain geometry
     //  with faces on the world box lists a good part of its hits for the exact check: grids for that)
@@ -2833,11 +2868,11 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (plain)
         hipLaunchKernelGGL((k_physics<false>), dim3(fblocks), dim3(PHYS_BLOCK_OF(false)), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
                            work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
-                           scatter_first, ctx->retry_list, 1, pc, rays_next);
+                           scatter_first, ctx->retry_list, 1, pc, rays_next, ctx->final_rec, ctx->final_epoch);
     else
         hipLaunchKernelGGL((k_physics<true>), dim3(fblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
                            work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
-                           scatter_first, ctx->retry_list, 1, pc, rays_next);
+                           scatter_first, ctx->retry_list, 1, pc, rays_next, ctx->final_rec, ctx->final_epoch);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(hipGetLastError());
     if (chained) std::swap(ctx->rays, ctx->rays_b);       // (what k_physics wrote is the next step's input)
@@ -3800,6 +3835,13 @@ static int ensure_queues(chroma_ctx *ctx, size_t n)
     HIP_TRY(hipMalloc((void **)&ctx->rays_b, (n + 1) * 4 * sizeof(float4)));
     HIP_TRY(hipMalloc((void **)&ctx->work_a, (n + 1) * 4 * sizeof(float4)));
     HIP_TRY(hipMalloc((void **)&ctx->work_b, (n + 1) * 4 * sizeof(float4)));
+#if PHYS_ENDED_AOS
+    if (ctx->final_rec) hipFree(ctx->final_rec);
+    ctx->final_rec = nullptr;
+    HIP_TRY(hipMalloc((void **)&ctx->final_rec, (n + 1) * 4 * sizeof(float4)));
+    HIP_TRY(hipMemset(ctx->final_rec, 0, (n + 1) * 4 * sizeof(float4)));
+    ctx->final_epoch = 0;
+#endif
     ctx->queue_capacity = n + 1;
     return CHROMA_OK;
 }
@@ -3875,6 +3917,9 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     // fused tail kernel.  The live photons travel in the dense working set (k_load_working).
     const bool device_steps = ctx->split_tail != 0;
     if (device_steps) {
+#if PHYS_ENDED_AOS
+        ctx->final_epoch++;
+#endif
         HIP_TRY(hipMemsetAsync(ctx->d_step, 0, sizeof(StepState), ctx->stream));
         hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, in_q, 1u);
         hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, out_q, 1u);
@@ -3932,6 +3977,12 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
             unsigned blocks = (unsigned)std::min<long long>((n_upper + 255) / 256, 4096);
             hipLaunchKernelGGL(k_store_working, dim3(std::max(blocks, 1u)), dim3(256), 0, ctx->stream, geom->view, pv, in_q, work_in);
         }
+#if PHYS_ENDED_AOS
+        {
+            unsigned blocks = (unsigned)std::min<uint64_t>((nphotons + 255) / 256, 8192);
+            hipLaunchKernelGGL(k_store_final, dim3(blocks), dim3(256), 0, ctx->stream, pv, ctx->final_rec, (uint64_t)nphotons, ctx->final_epoch);
+        }
+#endif
         HIP_TRY(hipMemcpyAsync(ctx->h_step, ctx->d_step, sizeof(StepState), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         launches = ((const StepState *)ctx->h_step)->launches;

@@ -85,6 +85,17 @@ class Simulation(object):
         batch_end = gpu_photons.get() if keep_photons_end else None
         batch_hits = gpu_photons.get_flat_hits(self.gpu_geometry) if is_detector and (keep_hits or keep_flat_hits) else None
 
+        # the hits of each event: one stable sort by event index and slices of it (views) instead of one boolean mask
+        # over all hits per event (chroma/sim.py:118-121 does the latter: quadratic in the number of events)
+        per_event_hits = None
+        if batch_hits is not None:
+            if len(batch_events) == 1:
+                per_event_hits = [batch_hits]
+            else:
+                order = np.argsort(batch_hits.evidx, kind='stable')
+                sorted_hits = batch_hits[order]
+                cuts = np.searchsorted(sorted_hits.evidx, np.arange(len(batch_events) + 1))
+                per_event_hits = [sorted_hits[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
         for i, (ev, lo, hi) in enumerate(zip(batch_events, bounds[:-1], bounds[1:])):
             if not keep_photons_beg:
                 ev.photons_beg = None
@@ -104,7 +115,7 @@ class Simulation(object):
             if keep_photons_end:
                 ev.photons_end = batch_end[lo:hi]
             if batch_hits is not None:
-                ev_hits = batch_hits[batch_hits.evidx == i]
+                ev_hits = per_event_hits[i]
                 if keep_hits:
                     ev.hits = {int(ch): ev_hits[ev_hits.channel == ch] for ch in np.unique(ev_hits.channel)}
                 if keep_flat_hits:
