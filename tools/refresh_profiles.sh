@@ -27,6 +27,10 @@ rm -rf $out/pmc_FETCH_SIZE/*/*agent_info.csv
 PMC_GROUPS="1 2" PMC_TIMEOUT=300 tools/pmc.sh $out/pmc_sq python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $out/pmc_sq.txt 2>&1
 python tools/pmc_sq.py $out/pmc_sq c3:100000000:100 >> $out/pmc_traffic.txt
 rm -rf $out/pmc_sq/pass*/*/*agent_info.csv
+# memory-instruction mix and waits of k_physics (tools/pmc_physics.sh)
+CHROMA_BENCH_NO_EXACT=1 tools/pmc_physics.sh $out/pmc_physics_raw > $out/pmc_physics.txt 2>&1
+rm -rf $out/pmc_physics_raw
 python bench.py --no-cpu-baseline > $out/bench_c3_with_traffic.json 2> $out/bench_c3_with_traffic.log
+tools/isa_report.sh > $out/isa_resources.txt 2>/dev/null
 rm -rf /dev/shm/chroma_geo_cache
 cat $out/bench_*.json
