@@ -2,16 +2,21 @@
 # One GPU-box pass that refreshes the judged artefacts: GPU tests, the bench lines of every config, the
 # rocprofv3 kernel summary of the default bench command and its HBM-traffic counters (FETCH_SIZE / WRITE_SIZE in
 # separate --pmc passes, no trace flags beside them).  usage: tools/refresh_profiles.sh OUTDIR
+# (a gpurun call is limited to 20 minutes: PART=1 runs the tests and the bench lines, PART=2 the profiles; default both)
 set -u
 out=$1
+part=${PART:-12}
 mkdir -p $out
 export CHROMA_BENCH_GEOMETRY_CACHE=/dev/shm/chroma_geo_cache
+if [[ $part == *1* ]]; then
 timeout -k 10 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $out/gpu_tests.log 2>&1 || { tail -20 $out/gpu_tests.log; exit 1; }
 tail -1 $out/gpu_tests.log
 python bench.py > $out/bench_c3_default.json 2> $out/bench_c3_default.log || exit 1
 for cfg in tiny lite c5 detector; do
   python bench.py --config $cfg > $out/bench_$cfg.json 2> $out/bench_$cfg.log || exit 1
 done
+fi
+if [[ $part != *2* ]]; then rm -rf /dev/shm/chroma_geo_cache; cat $out/bench_*.json; exit 0; fi
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_c3 -- python3 bench.py --no-cpu-baseline > $out/rocprof_c3.json 2> $out/rocprof_c3.log || exit 1
 python tools/prof_summary.py $out/rocprof_c3 $out/rocprof_c3_default_summary.txt bench.py
