@@ -17,12 +17,13 @@ for cfg in tiny lite c5 detector; do
 done
 fi
 if [[ $part != *2* ]]; then rm -rf /dev/shm/chroma_geo_cache; cat $out/bench_*.json; exit 0; fi
+export CHROMA_BENCH_NO_EXACT=1      # (the profiles are of the default walk: no extra batch through the literal one)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_c3 -- python3 bench.py --no-cpu-baseline > $out/rocprof_c3.json 2> $out/rocprof_c3.log || exit 1
 python tools/prof_summary.py $out/rocprof_c3 $out/rocprof_c3_default_summary.txt bench.py
 rm -rf $out/rocprof_c3
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 300 CHROMA_BENCH_NO_EXACT=1 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $out/pmc_$c.stdout 2> $out/pmc_$c.stderr || exit 1
+  timeout -k 5 300 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $out/pmc_$c.stdout 2> $out/pmc_$c.stderr || exit 1
 done
 python tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE c3:100000000:100 > $out/pmc_traffic.txt
 python tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE c3:100000000:100:physics k_physics >> $out/pmc_traffic.txt
@@ -33,9 +34,9 @@ PMC_GROUPS="1 2" PMC_TIMEOUT=300 tools/pmc.sh $out/pmc_sq python3 bench.py --no-
 python tools/pmc_sq.py $out/pmc_sq c3:100000000:100 >> $out/pmc_traffic.txt
 rm -rf $out/pmc_sq/pass*/*/*agent_info.csv
 # memory-instruction mix and waits of k_physics (tools/pmc_physics.sh)
-CHROMA_BENCH_NO_EXACT=1 tools/pmc_physics.sh $out/pmc_physics_raw > $out/pmc_physics.txt 2>&1
+tools/pmc_physics.sh $out/pmc_physics_raw > $out/pmc_physics.txt 2>&1
 rm -rf $out/pmc_physics_raw
-python bench.py --no-cpu-baseline > $out/bench_c3_with_traffic.json 2> $out/bench_c3_with_traffic.log
+CHROMA_BENCH_NO_EXACT= python bench.py --no-cpu-baseline > $out/bench_c3_with_traffic.json 2> $out/bench_c3_with_traffic.log
 tools/isa_report.sh > $out/isa_resources.txt 2>/dev/null
 rm -rf /dev/shm/chroma_geo_cache
 cat $out/bench_*.json
