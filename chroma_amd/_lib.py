@@ -71,7 +71,8 @@ class PropagateStats(Structure):
     _fields_ = [('photon_steps', c_uint64), ('nodes_visited', c_uint64), ('triangles_tested', c_uint64),
                 ('launches', c_uint64), ('stack_overflows', c_uint64), ('kernel_ms', c_double),
                 ('raycast_ms', c_double), ('raycast_launches', c_uint64), ('stack_spills', c_uint64),
-                ('physics_ms', c_double), ('physics_launches', c_uint64)]
+                ('physics_ms', c_double), ('physics_launches', c_uint64), ('packet_ms', c_double), ('packet_launches', c_uint64),
+                ('packet_rays', c_uint64), ('packet_nodes_visited', c_uint64), ('packet_triangles_tested', c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -161,6 +162,7 @@ SIGNATURES = {
     'chroma_set_counting': (c_int32, [c_void_p, c_int32]),
     'chroma_set_walk': (c_int32, [c_void_p, c_int32]),
     'chroma_set_tail': (c_int32, [c_void_p, c_int32]),
+    'chroma_set_packet': (c_int32, [c_void_p, c_int32]),
 }
 
 _lib = None

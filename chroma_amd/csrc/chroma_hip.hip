@@ -103,6 +103,7 @@ struct chroma_ctx {
     int ray_chunk = 256, coop_chunk = 64;  // rays a persistent wave takes from the queue per atomic (big batches)
     int fused_tail = 1;                    // 0 (CHROMA_TAIL=split): the last photons also take one launch set per step
     int split_tail = 1;                    // 0 (CHROMA_TAIL=fused): chroma_propagate launches the fused kernel only, as the reference does
+    int packet_mode = 2;                   // k_raycast_packet for the first step: 0 never, 1 always, 2 when the photons are coherent (CHROMA_PACKET=off|on|auto)
     int wide_walk = CHROMA_WALK_QUAD;      // CHROMA_WALK_*: reference tree | wide tree with 1, 8 or 4 (default) lanes per ray
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
     // the one exchange of the path (per-channel hit arrays): an RCCL communicator over the node's GPUs
@@ -1030,9 +1031,11 @@ template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD_WAVES_PER_EU, QUAD_WAVES_PER_EU))) void
 k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint2 *spill_base, DeviceCounters *counters,
-               int big_chunk, int settle)
+               int big_chunk, int settle, const uint32_t *skip = nullptr)
 {
     // (`settle`: nobody has written the hit entries of the slots whose ray record says "not to be cast" yet)
+    // (`skip`: the step has been given to k_raycast_packet, launched before this kernel)
+    if (skip && *skip != 0u) return;
     const int nthreads = (int)st->n;
     if ((long long)blockIdx.x * 16 >= nthreads) return;
     uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
@@ -1580,6 +1583,180 @@ k_raycast_pair(GeoView g, const float4 *rays, int first_photon, StepState *st,
     }
 }
 
+// ---- the ray cast for COHERENT rays: one packet of 64 rays per wavefront ---------------------------------
+// The first step of a batch whose photons come in direction order from a common origin (tools.argsort_direction, as
+// chroma/benchmark.py:80-82 prepares them; a photon bomb; the Cherenkov cone of a track) is a third of the ray-cast
+// time of the whole batch, and its rays are as coherent as rays get: the 64 rays of consecutive slots cross the same
+// nodes down to the last levels of the tree.  k_raycast_quad cannot use that -- every ray keeps its own stack and pays
+// the per-visit bookkeeping alone.  Here a wavefront IS a packet: ONE traversal stack (LDS), ONE node fetch per visit
+// for all 64 rays (the node's eight entries are wave-uniform: scalar loads, SGPRs), every lane tests the eight boxes
+// against its own ray, leaf triangles are tested at once by all lanes whose ray enters the leaf box (64 of 64 lanes on a
+// uniform triangle record instead of 7-12 of 64), and the bookkeeping of a visit -- order of the children, push, pop --
+// is wave-uniform scalar work done once for 64 rays.
+// Same tree, same slab test, same (distance, rank) rule: a lane tests exactly the triangles whose leaf entry its OWN
+// ray passes in nodes its own ray entered (a stack entry carries the mask of the lanes that passed the node's box; the
+// others sit the visit out), so the argument of DESIGN.md section 3.1 applies lane by lane and the result is the
+// quad walk's bit for bit (tests/test_gpu_packet.py) -- whatever the rays look like.  Only the SPEED depends on their
+// coherence: a packet of unrelated rays visits the union of 64 traversals with a few lanes active each time, so the
+// kernel is used where the photons say they are coherent (k_load_working counts the waves whose rays share an origin
+// and lie within a narrow cone; chroma_propagate's first step only) and k_raycast_quad everywhere else.
+#ifndef PACKET_STACK
+#define PACKET_STACK 96      // entries of the packet's stack in LDS (node, box distance, lane mask): deeper trees keep the quad walk
+#endif
+// (wave-uniform reads through the constant address space: the compiler emits scalar loads, the data lands in SGPRs)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) u32x4_t *const_u32x4_p;
+typedef const __attribute__((address_space(4))) f32x4_t *const_f32x4_p;
+
+// minimum over the 64 lanes (every lane active), for non-negative floats and +inf
+__device__ inline float wave_min_f32(float v)
+{
+    v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));     // quad_perm [1,0,3,2]
+    v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));     // quad_perm [2,3,0,1]
+    v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));    // row_half_mirror
+    v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));    // row_mirror
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return __builtin_fminf(__builtin_fminf(a, b), __builtin_fminf(c, d));
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void
+k_raycast_packet(GeoView g, const float4 *rays, StepState *st, int32_t *hit_triangle, float *hit_distance,
+                 uint32_t *retry_list, DeviceCounters *counters, const uint32_t *use_packet)
+{
+    // (launched beside k_raycast_quad: the step's photons decide on the device which of the two has work to do)
+    if (*use_packet == 0u) return;
+    const uint32_t nthreads = st->n;
+    static_assert(PROP_BLOCK == WAVE, "one wave per workgroup");
+    __shared__ uint32_t s_node[PACKET_STACK];
+    __shared__ float s_t[PACKET_STACK];
+    __shared__ unsigned long long s_mask[PACKET_STACK];
+    const unsigned lane = lane_id();
+    const unsigned long long lane_bit = 1ull << lane;
+    const float inf = cm_inff();
+    LaneCounters cnt = {0, 0, 0, 0};
+    const const_u32x4_p wnodes = (const_u32x4_p)(uintptr_t)g.wnodes;
+    const const_f32x4_p tris = (const_f32x4_p)(uintptr_t)g.tri;
+
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&st->work, (uint32_t)WAVE);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= nthreads) break;
+        const uint32_t slot = base + lane;
+        // ---- this lane's ray
+        bool on = false;
+        float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f;
+        float rax = 0.f, ray_ = 0.f, raz = 0.f;
+        f32x2 rbx = {0.f, 0.f}, rby = {0.f, 0.f}, rbz = {0.f, 0.f};
+        uint32_t rsx = 0, rsy = 0, rsz = 0;
+        int last_hit = -1;
+        if (slot < nthreads) {
+            const float4 *r = rays + 4 * (size_t)slot;
+            const float4 r0 = r[0], r1 = r[1];
+            const int status = __float_as_int(r1.w);
+            if (status == 0) {
+                const float4 r2 = r[2], r3 = r[3];
+                ox = r0.x; oy = r0.y; oz = r0.z; dx = r1.x; dy = r1.y; dz = r1.z;
+                last_hit = __float_as_int(r0.w);
+                rax = r2.x; ray_ = r2.y; raz = r2.z;
+                const float mx = cm_fabsf(rax), my = cm_fabsf(ray_), mz = cm_fabsf(raz);
+                rbx = (f32x2){r3.x - mx, r3.x + mx}; rby = (f32x2){r3.y - my, r3.y + my}; rbz = (f32x2){r3.z - mz, r3.z + mz};
+                rsx = rax < 0.f ? 16u : 0u; rsy = ray_ < 0.f ? 16u : 0u; rsz = raz < 0.f ? 16u : 0u;
+                on = true;
+            } else {                                         // HIT_NAN, or HIT_RETRY: 1/d not moderate (as k_raycast_quad settles them)
+                hit_triangle[slot] = status;
+                hit_distance[slot] = 0.0f;
+                if (status == HIT_RETRY) retry_list[atomicAdd(&st->retry, 1u)] = slot;
+            }
+        }
+        int triangle_index = -1;
+        uint32_t best_rank = 0;
+        float prune_t = inf;
+        // ---- the packet's traversal: wave-uniform control flow from here to the end of the packet
+        int sp = 0;
+        uint32_t cur = 0u;
+        unsigned long long cur_mask = __ballot(on);
+        bool have = cur_mask != 0ull;
+        while (have) {
+            const bool here = (cur_mask & lane_bit) != 0ull;        // this lane's ray entered the node
+            uint4 e[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const u32x4_t v = wnodes[8 * (size_t)cur + j]; e[j] = make_uint4(v.x, v.y, v.z, v.w); }
+            if (COUNT && here) cnt.nodes += 8;
+            uint32_t nxt = WIDE_NONE;
+            float nxt_t = inf;
+            unsigned long long nxt_mask = 0ull;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t w = e[j].w;
+                if (w == WIDE_NONE) continue;                        // (uniform)
+                float tn, tf;
+                box_interval_signed(rax, ray_, raz, rsx, rsy, rsz, rbx, rby, rbz, e[j], tn, tf);
+                const bool pass = here & !(tn > tf) & !(tn > prune_t);
+                if ((int)w < 0) {                                    // a triangle (uniform)
+                    const uint32_t rec = w & 0x7FFFFFFFu;
+                    const bool test = pass & ((int)rec != last_hit);
+                    if (__any(test)) {
+                        const f32x4_t a = tris[TRI_STRIDE * (size_t)rec], b = tris[TRI_STRIDE * (size_t)rec + 1], c = tris[TRI_STRIDE * (size_t)rec + 2];
+                        if (test) {
+                            if (COUNT) cnt.tris++;
+                            float distance;
+                            if (intersect_triangle(mk3(ox, oy, oz), mk3(dx, dy, dz), mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance)) {
+                                const uint32_t rank = __float_as_uint(c.w);
+                                if (distance < prune_t || (distance == prune_t && rank < best_rank)) {
+                                    triangle_index = (int)rec;
+                                    prune_t = distance;
+                                    best_rank = rank;
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    const unsigned long long m = __ballot(pass);
+                    if (m != 0ull) {
+                        const float t = wave_min_f32(pass ? tn : inf);      // the box distance of the nearest of the rays that enter
+                        uint32_t pn = w; float pt = t; unsigned long long pm = m;
+                        if (t < nxt_t) { pn = nxt; pt = nxt_t; pm = nxt_mask; nxt = w; nxt_t = t; nxt_mask = m; }
+                        if (pn != WIDE_NONE) {
+                            if (sp < PACKET_STACK) { s_node[sp] = pn; s_t[sp] = pt; s_mask[sp] = pm; }
+                            sp++;
+                        }
+                    }
+                }
+            }
+            cur = nxt;
+            cur_mask = nxt_mask;
+            have = cur != WIDE_NONE;
+            // next entry that can still hold a nearer hit for one of the rays that entered its box
+            while (!have && sp > 0) {
+                sp--;
+                if (sp >= PACKET_STACK) continue;                    // (cannot happen: the host checked the tree's need)
+                const float t = s_t[sp];
+                const unsigned long long m = s_mask[sp] & __ballot(!(t > prune_t));
+                if (m != 0ull) { cur = s_node[sp]; cur_mask = m; have = true; }
+            }
+        }
+        if (on) {
+            hit_triangle[slot] = triangle_index;
+            hit_distance[slot] = triangle_index == -1 ? -1.0f : prune_t;
+            if (COUNT) cnt.steps++;
+        }
+    }
+    if (COUNT) {
+        unsigned long long nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris), ry = wave_sum_u64(cnt.steps);
+        if (lane == 0) {
+            atomicAdd(&counters->nodes_visited, nd);
+            atomicAdd(&counters->triangles_tested, tr);
+            atomicAdd(&counters->packet_nodes, nd);
+            atomicAdd(&counters->packet_tris, tr);
+            atomicAdd(&counters->packet_rays, ry);
+        }
+    }
+}
+
 // ---- fused tail: all remaining steps of the last few photons, eight lanes per photon ---------------
 // Once fewer than 64*16*8 photons are alive the reference finishes them in ONE launch
 // (chroma/gpu/photon.py:227-230).  Per-step launches are a poor fit for that tail -- a few thousand
@@ -2077,10 +2254,14 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
 // ncopies clones of a photon next to each other); photons that are already terminal are left out -- and
 // thereby untouched (propagate.cu:258).
 __global__ __launch_bounds__(PHYS_BLOCK) void
-k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t n, uint32_t ncopies, uint32_t true_n, float4 *rays)
+k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t n, uint32_t ncopies, uint32_t true_n, float4 *rays,
+               uint32_t *coherence)
 {
     // (`rays`: also the ray records of the first step -- the first launch of a call always re-normalises)
+    // (`coherence`: [0] += waves whose photons share an origin and lie within a cone of 50 mrad, [1] += waves looked at:
+    //  what decides between k_raycast_packet and k_raycast_quad for the first step.  A heuristic: it steers speed only.)
     __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
+    uint32_t coh_yes = 0, coh_all = 0;
     for (uint64_t block_base = (uint64_t)blockIdx.x * PHYS_BLOCK; block_base < n; block_base += (uint64_t)gridDim.x * PHYS_BLOCK) {
         uint64_t j = block_base + threadIdx.x;
         bool take = false;
@@ -2101,9 +2282,34 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
             w[2] = make_float4(pol.x, pol.y, pol.z, pv.weights[photon_id]);
             w[3] = make_float4(__uint_as_float(flags), __uint_as_float(pv.rng_counters[photon_id]), __int_as_float(lh), __uint_as_float(photon_id));
             if (rays) make_ray_record(g, rays + 4 * (size_t)(at - 1u), pos, dir, 1, lh);
+            if (coherence) {
+                // against the wave's first taken lane (the lanes of a wave land in consecutive slots)
+                const unsigned long long m = __ballot(true);
+                const int first = __ffsll((long long)m) - 1;
+                const float px = __shfl(pos.x, first), py = __shfl(pos.y, first), pz = __shfl(pos.z, first);
+                const float qx = __shfl(dir.x, first), qy = __shfl(dir.y, first), qz = __shfl(dir.z, first);
+                const float d2 = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z, q2 = qx * qx + qy * qy + qz * qz;
+                const float c = dir.x * qx + dir.y * qy + dir.z * qz;
+                const bool near = fabsf(pos.x - px) + fabsf(pos.y - py) + fabsf(pos.z - pz) < 1.0f && c > 0.0f && c * c > 0.9975f * d2 * q2;
+                const unsigned long long ok = __ballot(near);
+                if ((int)lane_id() == first && __popcll(m) >= 32) { coh_all++; coh_yes += (ok == m) ? 1u : 0u; }
+            }
         }
         __syncthreads();
     }
+    if (coherence) {
+        if (coh_all) { atomicAdd(&coherence[1], coh_all); if (coh_yes) atomicAdd(&coherence[0], coh_yes); }
+    }
+}
+
+// which ray cast takes the first step: the packet kernel when three quarters of the waves are coherent (and the batch
+// is large enough for its persistent grid); `mode` 1 = always, 0 = never (CHROMA_PACKET=on|off)
+__global__ void k_packet_decide(const uint32_t *coherence, uint32_t *use_packet, uint64_t n, int mode)
+{
+    uint32_t use = 0u;
+    if (mode == 1) use = 1u;
+    else if (mode == 2) use = (n >= (1u << 18) && coherence[1] > 0u && 4ull * coherence[0] >= 3ull * coherence[1]) ? 1u : 0u;
+    *use_packet = use;
 }
 // the photons still alive when the call ends go back to the caller's arrays
 __global__ void k_store_working(GeoView g, PhotonView pv, const uint32_t *queue, const float4 *work)
@@ -2742,8 +2948,10 @@ static bool step_uses_quad_walk(const chroma_ctx *ctx, const chroma_geometry *ge
 // the step before).  With the default walk the records of the next step go to ctx->rays_b, and the two are swapped.
 static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, long long n_upper, const uint32_t *in_q,
                              uint32_t *out_q, const float4 *work_in, float4 *work_out, chroma_rng rng, int use_weights,
-                             int scatter_first, hipEvent_t *ev = nullptr, uint32_t first_n = 0, bool rays_ready = false)
+                             int scatter_first, hipEvent_t *ev = nullptr, uint32_t first_n = 0, bool rays_ready = false, bool packet = false)
 {
+    // (`packet`: the first step of a call whose k_load_working looked at the photons' coherence: k_raycast_packet is
+    //  launched before k_raycast_quad, and the word k_packet_decide wrote tells the two which of them has the step)
     if (n_upper <= 0) return CHROMA_OK;
     uint32_t need = geom->stack_need;
     if (need > STACK_LDS + STACK_SCRATCH)
@@ -2759,7 +2967,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
         unsigned sblocks = (unsigned)std::min<long long>((n_upper + 255) / 256, (long long)ctx->physics_blocks * 4);
         hipLaunchKernelGGL(k_ray_setup, dim3(sblocks), dim3(256), 0, ctx->stream, geom->view, work_in, st, ctx->rays,
                            ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, &st->retry);
-        if (ev) HIP_TRY(hipEventRecord(ev[3], ctx->stream));
+        if (ev) { HIP_TRY(hipEventRecord(ev[3], ctx->stream)); HIP_TRY(hipEventRecord(ev[5], ctx->stream)); }
         const unsigned lblocks = (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK, (long long)ctx->persistent_waves);
         if (ctx->counting)
             hipLaunchKernelGGL((k_raycast_retry<true, true>), dim3(lblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
@@ -2817,7 +3025,19 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     }
     const int settle = (chained && rays_ready) ? 1 : 0;
     float4 *rays_next = chained ? ctx->rays_b : nullptr;
-    if (ev) HIP_TRY(hipEventRecord(ev[3], ctx->stream));        // the ray-cast kernel proper is timed from here
+    if (ev) HIP_TRY(hipEventRecord(ev[3], ctx->stream));        // the ray-cast kernels proper are timed from here
+    const bool offer_packet = packet && chained && rays_ready;
+    const uint32_t *skip_quad = offer_packet ? ctx->d_words + 4 : nullptr;
+    if (offer_packet) {
+        const unsigned pwaves = (unsigned)std::min<long long>((n_upper + WAVE - 1) / WAVE, (long long)ctx->quad_waves);
+        if (ctx->counting)
+            hipLaunchKernelGGL((k_raycast_packet<true>), dim3(pwaves), block, 0, ctx->stream, geom->view, ctx->rays, st, ctx->hit_triangle,
+                               ctx->hit_distance, ctx->retry_list, ctx->d_counters, ctx->d_words + 4);
+        else
+            hipLaunchKernelGGL((k_raycast_packet<false>), dim3(pwaves), block, 0, ctx->stream, geom->view, ctx->rays, st, ctx->hit_triangle,
+                               ctx->hit_distance, ctx->retry_list, ctx->d_counters, ctx->d_words + 4);
+    }
+    if (ev) HIP_TRY(hipEventRecord(ev[5], ctx->stream));        // (k_raycast_packet before, the step's other ray cast after)
 #define RAYCAST_LAUNCH(COUNT)                                                                                          \
     do {                                                                                                               \
         if (pair)                                                                                                      \
@@ -2825,7 +3045,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
         else if (quad)                                                                                                 \
             hipLaunchKernelGGL((k_raycast_quad<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
-                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, settle); \
+                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, settle, skip_quad); \
         else if (coop)                                                                                                 \
             hipLaunchKernelGGL((k_raycast_coop<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
@@ -3106,6 +3326,7 @@ int chroma_init(int device, chroma_ctx **out)
             ctx->wide_walk = !strcmp(e, "reference") ? CHROMA_WALK_REFERENCE : !strcmp(e, "wide") ? CHROMA_WALK_WIDE
                            : !strcmp(e, "coop") ? CHROMA_WALK_COOP : !strcmp(e, "pair") ? CHROMA_WALK_PAIR
                            : (!strcmp(e, "literal") || !strcmp(e, "exact")) ? CHROMA_WALK_LITERAL : CHROMA_WALK_QUAD;
+        if (const char *e = getenv("CHROMA_PACKET")) ctx->packet_mode = !strcmp(e, "off") ? 0 : !strcmp(e, "on") ? 1 : 2;
         if (const char *e = getenv("CHROMA_RAY_CHUNK")) ctx->ray_chunk = std::max(64, atoi(e));
         if (const char *e = getenv("CHROMA_COOP_CHUNK")) ctx->coop_chunk = std::max(8, atoi(e));
         if (const char *e = getenv("CHROMA_TAIL")) {      // coop (default) | split | fused (the lane-per-photon k_propagate)
@@ -3858,6 +4079,9 @@ int chroma_propagate_stats_read(chroma_ctx *ctx, chroma_propagate_stats *stats)
     stats->triangles_tested += c.triangles_tested;
     stats->stack_overflows += c.stack_overflows;
     stats->stack_spills += c.stack_spills;
+    stats->packet_rays += c.packet_rays;
+    stats->packet_nodes_visited += c.packet_nodes;
+    stats->packet_triangles_tested += c.packet_tris;
     return CHROMA_OK;
 }
 
@@ -3875,6 +4099,14 @@ int chroma_set_walk(chroma_ctx *ctx, int32_t mode)
         mode != CHROMA_WALK_PAIR && mode != CHROMA_WALK_LITERAL)
         return set_error(CHROMA_ERR_INVALID, "unknown walk mode %d", mode);
     ctx->wide_walk = mode;
+    return CHROMA_OK;
+}
+
+int chroma_set_packet(chroma_ctx *ctx, int32_t mode)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    if (mode < 0 || mode > 2) return set_error(CHROMA_ERR_INVALID, "unknown packet mode %d", mode);
+    ctx->packet_mode = mode;
     return CHROMA_OK;
 }
 
@@ -3904,8 +4136,9 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     uint32_t *in_q = ctx->queue_a, *out_q = ctx->queue_b;
     float4 *work_in = ctx->work_a, *work_out = ctx->work_b;
 
-    double kernel_ms = 0.0, raycast_ms = 0.0, physics_ms = 0.0;
-    uint64_t launches = 0, raycast_launches = 0, physics_launches = 0;
+    double kernel_ms = 0.0, raycast_ms = 0.0, physics_ms = 0.0, packet_ms = 0.0;
+    uint64_t launches = 0, raycast_launches = 0, physics_launches = 0, packet_launches = 0;
+    bool packet_offered = false;
     // Launch policy of the reference (chroma/gpu/photon.py:225-252): one step per launch while many
     // photons are alive, and ONE launch for all remaining steps once fewer than 64*16*8 are left (or
     // with weights).  A launch re-normalises dir/pol when it loads a photon (propagate.cu:248,250), so
@@ -3925,12 +4158,17 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, out_q, 1u);
         {
             unsigned blocks = (unsigned)std::min<uint64_t>((nphotons + PHYS_BLOCK - 1) / PHYS_BLOCK, (uint64_t)ctx->physics_blocks);
+            const bool probe = step_uses_quad_walk(ctx, geom) && ctx->packet_mode != 0 && geom->wide_stack_need <= PACKET_STACK;
+            packet_offered = probe;
+            HIP_TRY(hipMemsetAsync(ctx->d_words + 4, 0, 12, ctx->stream));          // [4] use_packet, [5] coherent waves, [6] waves
             hipLaunchKernelGGL(k_load_working, dim3(blocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, in_q, work_in,
                                (uint64_t)nphotons, ncopies, (uint32_t)(nphotons / ncopies),
-                               step_uses_quad_walk(ctx, geom) ? ctx->rays : nullptr);
+                               step_uses_quad_walk(ctx, geom) ? ctx->rays : nullptr, (probe && ctx->packet_mode == 2) ? ctx->d_words + 5 : nullptr);
+            if (probe)
+                hipLaunchKernelGGL(k_packet_decide, dim3(1), dim3(1), 0, ctx->stream, ctx->d_words + 5, ctx->d_words + 4, (uint64_t)nphotons, ctx->packet_mode);
         }
         HIP_TRY(hipGetLastError());
-        const int nev = time_kernels ? 5 * max_steps : 0;
+        const int nev = time_kernels ? 6 * max_steps : 0;
         while ((int)ctx->step_events.size() < nev) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->step_events.push_back(e); }
         long long n_upper = (long long)nphotons;
         int step = 0, next_check = 1, steps_timed = 0;
@@ -3944,7 +4182,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                 // the reference's last launch: all remaining steps at once, 8 lanes per photon
                 bool launched = false;
                 rc = launch_tail(ctx, geom, pv, n_upper, in_q, out_q, work_in, rng, max_steps - step, use_weights,
-                                 step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 5 * step : nullptr, &launched,
+                                 step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 6 * step : nullptr, &launched,
                                  step == 0 ? (uint32_t)nphotons : 0u);
                 if (rc) return rc;
                 if (launched) {
@@ -3955,8 +4193,8 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                 }
             }
             rc = launch_split_step(ctx, geom, pv, n_upper, in_q, out_q, work_in, work_out, rng, use_weights,
-                                   step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 5 * step : nullptr,
-                                   step == 0 ? (uint32_t)nphotons : 0u, step_uses_quad_walk(ctx, geom));
+                                   step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 6 * step : nullptr,
+                                   step == 0 ? (uint32_t)nphotons : 0u, step_uses_quad_walk(ctx, geom), step == 0 && packet_offered);
             if (rc) return rc;
             if (time_kernels) steps_timed = step + 1;
             step++;
@@ -3988,13 +4226,18 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         launches = ((const StepState *)ctx->h_step)->launches;
         for (int k = 0; k < steps_timed; k++) {
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[5 * k], ctx->step_events[5 * k + 2]));
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[6 * k], ctx->step_events[6 * k + 2]));
             kernel_ms += ms;
             if (k == tail_step) continue;             // the fused tail is not a ray-cast launch
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[5 * k + 3], ctx->step_events[5 * k + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[6 * k + 5], ctx->step_events[6 * k + 1]));
             raycast_ms += ms;
             raycast_launches++;
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[5 * k + 1], ctx->step_events[5 * k + 4]));
+            if (k == 0 && packet_offered) {           // the first step's k_raycast_packet launch (an empty one when the photons are not coherent)
+                HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[6 * k + 3], ctx->step_events[6 * k + 5]));
+                packet_ms += ms;
+                packet_launches++;
+            }
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->step_events[6 * k + 1], ctx->step_events[6 * k + 4]));
             physics_ms += ms;                         // the main pass of k_physics (not the fix-up pass)
             physics_launches++;
         }
@@ -4052,6 +4295,8 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         stats->raycast_launches += raycast_launches;
         stats->physics_ms += physics_ms;
         stats->physics_launches += physics_launches;
+        stats->packet_ms += packet_ms;
+        stats->packet_launches += packet_launches;
         if (stats->stack_overflows) return set_error(CHROMA_ERR_STACK, "traversal stack overflowed for %llu rays", (unsigned long long)stats->stack_overflows);
     } else {
         chroma_propagate_stats tmp; memset(&tmp, 0, sizeof tmp);

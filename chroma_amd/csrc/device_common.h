@@ -92,6 +92,7 @@ struct PhotonView {   // device pointers of chroma_photon_arrays
 struct DeviceCounters {   // accumulated with one atomic per wave
     unsigned long long photon_steps, nodes_visited, triangles_tested, stack_overflows;
     unsigned long long stack_spills;   // stack entries a fast walk pushed beyond its LDS part (counting builds)
+    unsigned long long packet_rays, packet_nodes, packet_tris;      // k_raycast_packet's share of the two counts above (counting builds)
 };
 
 // ---- wave-level helpers --------------------------------------------------------------------

@@ -108,6 +108,12 @@ class Context(object):
             self._walk = w = w if w in self.WALKS else 'quad'
         return w
 
+    def set_packet(self, mode):
+        """'auto' (default), 'on' or 'off': whether the FIRST step of a propagate call goes to the packet ray cast (64
+        rays per wavefront as one packet: same results, fast for coherent photons -- a direction-sorted bomb --, slow
+        for unrelated ones).  'auto' decides per call from the photons themselves."""
+        _lib.check(self._lib.chroma_set_packet(self.handle, {'off': 0, 'on': 1, 'auto': 2}[mode]))
+
     def set_tail(self, mode):
         """'coop' (default), 'split' or 'fused': how propagate() finishes -- or, with 'fused', runs -- a batch."""
         _lib.check(self._lib.chroma_set_tail(self.handle, {'coop': 0, 'split': 1, 'fused': 2}[mode]))

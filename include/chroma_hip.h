@@ -168,6 +168,10 @@ typedef struct chroma_propagate_stats {
                                     (counting mode only; the deep-stack path of the 4- and 8-lane walks) */
     double   physics_ms;         /* HIP-event time of the main k_physics pass of every timed step            */
     uint64_t physics_launches;
+    double   packet_ms;          /* HIP-event time of k_raycast_packet (the first step of a call with coherent photons);
+                                    raycast_ms / raycast_launches then are k_raycast_quad's alone               */
+    uint64_t packet_launches;
+    uint64_t packet_rays, packet_nodes_visited, packet_triangles_tested;   /* counting mode: the packet kernel's share */
 } chroma_propagate_stats;
 
 const char *chroma_last_error(void);
@@ -457,6 +461,17 @@ int chroma_set_counting(chroma_ctx *ctx, int32_t enabled);
 #define CHROMA_WALK_PAIR      4   /* the wide tree with two lanes per ray, four child entries per lane  */
 #define CHROMA_WALK_LITERAL   5   /* chroma/cuda/mesh.h:42-118 literally, for every ray: exact, slow */
 int chroma_set_walk(chroma_ctx *ctx, int32_t mode);
+
+/* The first step of a chroma_propagate call can go to k_raycast_packet: 64 rays per wavefront walk the wide tree as ONE
+ * packet (one stack, scalar node fetches, every triangle tested by all lanes whose ray enters its box) -- the same
+ * results as the default walk, lane by lane, whatever the rays; much faster when the photons of neighbouring slots are
+ * coherent (a direction-sorted bomb as chroma/benchmark.py:80-82 prepares it, a Cherenkov cone), much slower when they
+ * are not.  AUTO (default): k_load_working looks at the photons (same origin, within 50 mrad, per wave of 64) and the
+ * packet kernel takes the step when three quarters of the waves are coherent.  Env CHROMA_PACKET=auto|on|off. */
+#define CHROMA_PACKET_OFF  0
+#define CHROMA_PACKET_ON   1
+#define CHROMA_PACKET_AUTO 2
+int chroma_set_packet(chroma_ctx *ctx, int32_t mode);
 
 /* How chroma_propagate finishes a batch and, with FUSED, how it runs it at all (same results; for
  * tests and benchmarks).  COOP: per-step launch sets, then ONE cooperative launch for all remaining

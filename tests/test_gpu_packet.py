@@ -1,0 +1,102 @@
+"""k_raycast_packet: the first step of a propagate call with 64 rays per wavefront walking the wide tree as one packet.
+Whatever the rays look like, every photon must come out as the default (quad) walk and the oracle give it, bit for bit;
+only the speed depends on coherence.  'auto' must pick the packet kernel for a direction-sorted bomb and leave an
+unsorted one to the quad walk."""
+import numpy as np
+import pytest
+
+from chroma_amd import event
+from conftest import bomb
+from test_gpu_parity import assert_bit_exact, _edge_photons
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    from chroma_amd import gpu as g
+    ctx = g.create_cuda_context(0)
+    yield g
+    ctx.set_packet('auto')
+    ctx.pop()
+
+
+def _propagate(gpu, gg, photons, mode, seed=4242, max_steps=100, sort=False, counting=True):
+    ctx = gpu.get_context()
+    ctx.set_packet(mode)
+    gp = gpu.GPUPhotons(photons)
+    if sort:
+        gp.sort_by_direction()
+    stats = {}
+    ctx.set_counting(counting)
+    try:
+        gp.propagate(gg, gpu.get_rng_states(64, seed=seed), max_steps=max_steps, stats=stats)
+    finally:
+        ctx.set_counting(False)
+        ctx.set_packet('auto')
+    return gp, gp.get(), stats
+
+
+@pytest.mark.parametrize('geometry_name', ['tiny', 'lite'])
+def test_packet_walk_equals_quad_walk_and_oracle(gpu, oracle_mod, tiny_geometry, geometry_name):
+    from chroma_amd import demo
+    from chroma_amd.loader import create_geometry_from_obj
+    from chroma_amd.gpu.geometry import pack_geometry
+    geo = tiny_geometry if geometry_name == 'tiny' else create_geometry_from_obj(demo.detector_lite())
+    packed = pack_geometry(geo)
+    gg = gpu.GPUDetector(geo, packed=packed)
+    n = 300000
+    ph = oracle_mod.generate_bomb(n, seed=11, id_base=0)
+    # (a) coherent rays: the bomb in direction order -- sorted on the device, read back, so that oracle and engine see the same photons
+    gps = gpu.GPUPhotons(ph)
+    gps.sort_by_direction()
+    sorted_ph = gps.get()
+    want, counters, ostats = oracle_mod.propagate(packed, sorted_ph, seed=4242, max_steps=100, nthreads=8)
+    for mode in ('on', 'off', 'auto'):
+        gp, got, stats = _propagate(gpu, gg, sorted_ph, mode)
+        assert_bit_exact(got, want, '%s: sorted bomb, packet %s' % (geometry_name, mode))
+        assert np.array_equal(gp.rng_counters.get(), counters)
+        assert stats['photon_steps'] == ostats['photon_steps'] and stats['launches'] == ostats['launches']
+        took = stats['packet_rays']
+        assert (took == n) if mode in ('on', 'auto') else (took == 0), (mode, took)
+        if mode == 'on':
+            # a lane counts the nodes ITS ray entered and the triangles it tested: the same kind of numbers as the quad walk's
+            assert 0 < stats['packet_nodes_visited'] <= stats['nodes_visited'] and 0 < stats['packet_triangles_tested'] <= stats['triangles_tested']
+    # (b) unrelated rays in one packet: the same photons in generation order.  Forced on: correct all the same; auto: left to the quad walk
+    want, counters, ostats = oracle_mod.propagate(packed, ph, seed=4242, max_steps=100, nthreads=8)
+    for mode in ('on', 'auto'):
+        gp, got, stats = _propagate(gpu, gg, ph, mode)
+        assert_bit_exact(got, want, '%s: unsorted bomb, packet %s' % (geometry_name, mode))
+        assert np.array_equal(gp.rng_counters.get(), counters)
+        assert stats['packet_rays'] == (n if mode == 'on' else 0)
+
+
+def test_packet_walk_on_awkward_photons(gpu, oracle_mod, tiny_geometry):
+    """Terminal, NaN, axis-parallel, outside-the-world photons and photons with a last hit, mixed into the packets
+    (the slots the ray cast must settle instead of casting), and a second propagate call whose first step starts ON
+    triangles with last hits set."""
+    from chroma_amd.gpu.geometry import pack_geometry
+    packed = pack_geometry(tiny_geometry)
+    gg = gpu.GPUDetector(tiny_geometry, packed=packed)
+    ph = _edge_photons()
+    want, counters, _ = oracle_mod.propagate(packed, ph, seed=4242, max_steps=20, nthreads=8)
+    gp, got, stats = _propagate(gpu, gg, ph, 'on', max_steps=20)
+    assert_bit_exact(got, want, 'edge inputs through the packet walk')
+    assert np.array_equal(gp.rng_counters.get(), counters)
+    assert stats['packet_rays'] > 20000
+    # photons that have taken one step (they sit on triangles, last_hit_triangles set) start a NEW call: its first step is a packet step
+    ph2 = bomb(100000, 23)
+    one, ctr1, _ = oracle_mod.propagate(packed, ph2, seed=4242, max_steps=1, nthreads=8)
+    two, ctr2, _ = oracle_mod.propagate(packed, one, seed=4242, max_steps=100, nthreads=8, rng_counters=ctr1)
+    ctx = gpu.get_context()
+    gp = gpu.GPUPhotons(ph2)
+    rs = gpu.get_rng_states(64, seed=4242)
+    ctx.set_packet('on')
+    try:
+        gp.propagate(gg, rs, max_steps=1)
+        assert_bit_exact(gp.get(), one, 'first call')
+        gp.propagate(gg, rs, max_steps=100)
+    finally:
+        ctx.set_packet('auto')
+    assert_bit_exact(gp.get(), two, 'second call: rays starting on their last hit')
+    assert np.array_equal(gp.rng_counters.get(), ctr2)
