@@ -103,7 +103,7 @@ struct chroma_ctx {
     int ray_chunk = 256, coop_chunk = 64;  // rays a persistent wave takes from the queue per atomic (big batches)
     int fused_tail = 1;                    // 0 (CHROMA_TAIL=split): the last photons also take one launch set per step
     int split_tail = 1;                    // 0 (CHROMA_TAIL=fused): chroma_propagate launches the fused kernel only, as the reference does
-    int packet_mode = 2;                   // k_raycast_packet for the first step: 0 never, 1 always, 2 when the photons are coherent (CHROMA_PACKET=off|on|auto)
+    int packet_mode = 0;                   // k_raycast_packet for the first step: 0 never (default: it is not faster, profiles/r03/ab_packet_first_step.txt), 1 always, 2 when the photons are coherent (CHROMA_PACKET=off|on|auto)
     int wide_walk = CHROMA_WALK_QUAD;      // CHROMA_WALK_*: reference tree | wide tree with 1, 8 or 4 (default) lanes per ray
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
     // the one exchange of the path (per-channel hit arrays): an RCCL communicator over the node's GPUs
@@ -1598,8 +1598,12 @@ k_raycast_pair(GeoView g, const float4 *rays, int first_photon, StepState *st,
 // others sit the visit out), so the argument of DESIGN.md section 3.1 applies lane by lane and the result is the
 // quad walk's bit for bit (tests/test_gpu_packet.py) -- whatever the rays look like.  Only the SPEED depends on their
 // coherence: a packet of unrelated rays visits the union of 64 traversals with a few lanes active each time, so the
-// kernel is used where the photons say they are coherent (k_load_working counts the waves whose rays share an origin
-// and lie within a narrow cone; chroma_propagate's first step only) and k_raycast_quad everywhere else.
+// kernel can be switched in where the photons say they are coherent (k_load_working counts the waves whose rays share
+// an origin and lie within a narrow cone; chroma_propagate's first step only).
+// MEASURED (profiles/r03/ab_packet_first_step.txt, pmc_packet.txt): 31.3 ms for the 1e8 direction-sorted rays of a C3
+// batch's first step against 29.5 ms for k_raycast_quad -- the slab work per (ray, entry) pair is the same in both, and
+// what a packet saves in bookkeeping it pays for the UNION of its rays' paths (~40 nodes, ~35 triangles per packet where
+// one ray needs 19 and 9.4).  So it is an opt-in (CHROMA_PACKET=on|auto, chroma_set_packet), off by default.
 #ifndef PACKET_STACK
 #define PACKET_STACK 96      // entries of the packet's stack in LDS (node, box distance, lane mask): deeper trees keep the quad walk
 #endif
@@ -3326,7 +3330,7 @@ int chroma_init(int device, chroma_ctx **out)
             ctx->wide_walk = !strcmp(e, "reference") ? CHROMA_WALK_REFERENCE : !strcmp(e, "wide") ? CHROMA_WALK_WIDE
                            : !strcmp(e, "coop") ? CHROMA_WALK_COOP : !strcmp(e, "pair") ? CHROMA_WALK_PAIR
                            : (!strcmp(e, "literal") || !strcmp(e, "exact")) ? CHROMA_WALK_LITERAL : CHROMA_WALK_QUAD;
-        if (const char *e = getenv("CHROMA_PACKET")) ctx->packet_mode = !strcmp(e, "off") ? 0 : !strcmp(e, "on") ? 1 : 2;
+        if (const char *e = getenv("CHROMA_PACKET")) ctx->packet_mode = !strcmp(e, "on") ? 1 : !strcmp(e, "auto") ? 2 : 0;
         if (const char *e = getenv("CHROMA_RAY_CHUNK")) ctx->ray_chunk = std::max(64, atoi(e));
         if (const char *e = getenv("CHROMA_COOP_CHUNK")) ctx->coop_chunk = std::max(8, atoi(e));
         if (const char *e = getenv("CHROMA_TAIL")) {      // coop (default) | split | fused (the lane-per-photon k_propagate)

@@ -109,9 +109,10 @@ class Context(object):
         return w
 
     def set_packet(self, mode):
-        """'auto' (default), 'on' or 'off': whether the FIRST step of a propagate call goes to the packet ray cast (64
-        rays per wavefront as one packet: same results, fast for coherent photons -- a direction-sorted bomb --, slow
-        for unrelated ones).  'auto' decides per call from the photons themselves."""
+        """'off' (default), 'on' or 'auto': whether the FIRST step of a propagate call goes to the packet ray cast (64
+        rays per wavefront as one packet: same results; measured no faster than the default walk even for a
+        direction-sorted bomb, much slower for unrelated rays: an opt-in experiment).  'auto' decides per call from the
+        photons themselves."""
         _lib.check(self._lib.chroma_set_packet(self.handle, {'off': 0, 'on': 1, 'auto': 2}[mode]))
 
     def set_tail(self, mode):

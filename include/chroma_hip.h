@@ -466,8 +466,11 @@ int chroma_set_walk(chroma_ctx *ctx, int32_t mode);
  * packet (one stack, scalar node fetches, every triangle tested by all lanes whose ray enters its box) -- the same
  * results as the default walk, lane by lane, whatever the rays; much faster when the photons of neighbouring slots are
  * coherent (a direction-sorted bomb as chroma/benchmark.py:80-82 prepares it, a Cherenkov cone), much slower when they
- * are not.  AUTO (default): k_load_working looks at the photons (same origin, within 50 mrad, per wave of 64) and the
- * packet kernel takes the step when three quarters of the waves are coherent.  Env CHROMA_PACKET=auto|on|off. */
+ * are not.  AUTO: k_load_working looks at the photons (same origin, within 50 mrad, per wave of 64) and the packet kernel
+ * takes the step when three quarters of the waves are coherent.  OFF is the default: measured on the 29k-PMT detector the
+ * packet kernel is no faster than the default walk even on perfectly coherent rays (31.3 against 29.5 ms per 1e8 rays,
+ * profiles/r03/ab_packet_first_step.txt: the union of 64 paths costs what the shared bookkeeping saves), so it stays an
+ * opt-in with its parity tests.  Env CHROMA_PACKET=off|on|auto. */
 #define CHROMA_PACKET_OFF  0
 #define CHROMA_PACKET_ON   1
 #define CHROMA_PACKET_AUTO 2
