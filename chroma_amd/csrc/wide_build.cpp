@@ -548,6 +548,173 @@ static int sah_topology(const uint32_t *ref, uint32_t ntriangles, const std::vec
     return 0;
 }
 
+// ---- PLOC: the hierarchy built bottom-up ------------------------------------------------------------------
+// Parallel locally-ordered clustering (Meister & Bittner, "Parallel Locally-Ordered Clustering for Bounding Volume
+// Hierarchy Construction", TVCG 2018): the clusters -- at first the reference's leaves in their Morton order, which is
+// the order of the reference tree's last layer -- each look PLOC_RADIUS places to either side for the neighbour whose
+// union with them has the least area (ties: the lower index); two clusters that chose each other merge into a binary
+// node that takes the place of the lower one; repeat until one cluster is left.  Every step is a data-parallel pass
+// over an array, which is why the device builder (csrc/wide_device.hip) runs exactly this; areas are integers, node
+// numbers come from prefix counts, so host and device give the same tree bit for bit.  The binary tree is then cut into
+// eight-wide nodes by the same least-area dynamic programme as the SAH topology, and the wide nodes are numbered
+// breadth first (a level's nodes in the order of their parents' entries).
+struct PlocCluster { uint16_t lo[3], hi[3]; uint32_t node; };
+
+static inline uint64_t ploc_union_area(const PlocCluster &a, const PlocCluster &b)
+{
+    uint64_t d[3];
+    for (int k = 0; k < 3; k++) d[k] = (uint64_t)(std::max(a.hi[k], b.hi[k]) - std::min(a.lo[k], b.lo[k]));
+    return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+}
+
+// D(n, k) of a binary node whose children's rows are filled (see build_subtree_dp)
+static inline void dp_fill_node(DpScratch &d, size_t n)
+{
+    const BinNode &b = d.bin[n];
+    const float *cl = &d.cost[(size_t)b.left * 8], *cr = &d.cost[(size_t)b.right * 8];
+    float *cn = &d.cost[n * 8];
+    float share[9]; uint8_t share_j[9];
+    for (int k = 2; k <= 8; k++) {
+        float best = 0.0f; int bj = 0;
+        for (int j = 1; j < k; j++) {
+            const float c = cl[j - 1] + cr[k - j - 1];
+            if (bj == 0 || c < best) { best = c; bj = j; }
+        }
+        share[k] = best; share_j[k] = (uint8_t)bj;
+    }
+    const float own = (float)bin_area(b) + share[8];
+    cn[0] = own;
+    d.left_share[n * 8] = share_j[8];
+    d.own_node[n * 8] = 1;
+    for (int k = 2; k <= 8; k++) {
+        if (own <= share[k]) { cn[k - 1] = own; d.own_node[n * 8 + (k - 1)] = 1; d.left_share[n * 8 + (k - 1)] = share_j[8]; }
+        else { cn[k - 1] = share[k]; d.left_share[n * 8 + (k - 1)] = share_j[k]; }
+    }
+}
+
+static int ploc_topology(const uint32_t *ref, size_t leaf_lo, size_t leaf_hi, uint32_t ntriangles, WideTree &out, std::string &err)
+{
+    const size_t n = leaf_hi - leaf_lo;
+    if (n == 0 || n > 0x3FFFFFFFull) { err = "wide tree: no leaves, or too many"; return -1; }
+    DpScratch d;
+    d.bin.resize(2 * n - 1);
+    out.dev_to_tri.resize(n);
+    std::vector<PlocCluster> cur(n), nxt;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t *nd = ref + 4 * (leaf_lo + i);
+        if ((nd[3] >> NCHILD_SHIFT) != 0 || (nd[3] & CHILD_MASK) >= ntriangles) { err = "wide tree: the last layer of the reference tree is not a layer of leaves"; return -1; }
+        PlocCluster c;
+        for (int a = 0; a < 3; a++) { c.lo[a] = (uint16_t)(nd[a] & 0xFFFFu); c.hi[a] = (uint16_t)(nd[a] >> 16); }
+        c.node = (uint32_t)i;
+        cur[i] = c;
+        BinNode &b = d.bin[i];
+        for (int a = 0; a < 3; a++) { b.lo[a] = c.lo[a]; b.hi[a] = c.hi[a]; }
+        b.left = BIN_LEAF; b.right = (uint32_t)i;
+        out.dev_to_tri[i] = nd[3] & CHILD_MASK;
+    }
+    d.cost.assign((2 * n - 1) * 8, 0.0f);
+    d.left_share.assign((2 * n - 1) * 8, 0);
+    d.own_node.assign((2 * n - 1) * 8, 0);
+    size_t nb = n;                       // binary nodes so far: the leaves
+    const size_t radius = getenv("CHROMA_PLOC_RADIUS") ? (size_t)std::max(1, atoi(getenv("CHROMA_PLOC_RADIUS"))) : (size_t)PLOC_RADIUS;
+    std::vector<uint32_t> nn;
+    while (cur.size() > 1) {
+        const size_t m = cur.size();
+        nn.resize(m);
+        parallel_for(m, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                const size_t lo = i > radius ? i - radius : 0, hi = std::min(m - 1, i + radius);
+                uint64_t best = ~0ull; size_t bj = i;
+                for (size_t j = lo; j <= hi; j++) {
+                    if (j == i) continue;
+                    const uint64_t ar = ploc_union_area(cur[i], cur[j]);
+                    if (ar < best) { best = ar; bj = j; }
+                }
+                nn[i] = (uint32_t)bj;
+            }
+        }, 1u << 12);
+        nxt.clear();
+        nxt.reserve(m);
+        for (size_t i = 0; i < m; i++) {
+            const size_t j = nn[i];
+            const bool mutual = nn[j] == i;
+            if (mutual && j < i) continue;                       // merged into the lower one
+            if (!mutual) { nxt.push_back(cur[i]); continue; }
+            PlocCluster c;
+            for (int a = 0; a < 3; a++) { c.lo[a] = std::min(cur[i].lo[a], cur[j].lo[a]); c.hi[a] = std::max(cur[i].hi[a], cur[j].hi[a]); }
+            c.node = (uint32_t)nb;
+            BinNode &b = d.bin[nb];
+            for (int a = 0; a < 3; a++) { b.lo[a] = c.lo[a]; b.hi[a] = c.hi[a]; }
+            b.left = cur[i].node; b.right = cur[j].node;
+            dp_fill_node(d, nb);                                 // (the children were made in earlier passes)
+            nb++;
+            nxt.push_back(c);
+        }
+        if (nxt.size() == m) { err = "wide tree: clustering made no progress"; return -1; }      // (cannot happen: the least pair is mutual)
+        cur.swap(nxt);
+    }
+    // breadth-first emission
+    out.wnodes.clear();
+    std::vector<uint32_t> level(1, cur[0].node), next;
+    size_t base = 0;
+    uint32_t depth = 0;
+    if (n == 1) {                                                // a single triangle: one node, one leaf entry
+        out.wnodes.assign(32, 0);
+        for (int i = 0; i < (int)WIDE_K; i++) { uint32_t *o = out.wnodes.data() + 4 * i; o[0] = o[1] = o[2] = 0x0000FFFFu; o[3] = WIDE_EMPTY; }
+        const BinNode &b = d.bin[0];
+        for (int a = 0; a < 3; a++) out.wnodes[a] = (uint32_t)b.lo[a] | (uint32_t)b.hi[a] << 16;
+        out.wnodes[3] = WIDE_LEAF | 0u;
+        out.nwide = 1; out.depth = 1;
+        return 0;
+    }
+    while (!level.empty()) {
+        const size_t cnt = level.size();
+        if (base + cnt > 0x7FFFFFFFull) { err = "wide tree: more than 2^31 nodes"; return -1; }
+        out.wnodes.resize((base + cnt) * 32);
+        // entries of every node of the level, and how many inner children each has
+        std::vector<uint32_t> items(cnt * WIDE_K);
+        std::vector<uint8_t> nitems(cnt);
+        std::vector<uint32_t> first_child(cnt + 1, 0);
+        parallel_for(cnt, [&](size_t a, size_t e) {
+            for (size_t k = a; k < e; k++) {
+                const BinNode &b = d.bin[level[k]];
+                uint32_t *it = items.data() + k * WIDE_K;
+                int ni = 0;
+                const int j = d.left_share[(size_t)level[k] * 8];
+                emit_entries(d, b.left, j, it, ni);
+                emit_entries(d, b.right, (int)WIDE_K - j, it, ni);
+                nitems[k] = (uint8_t)ni;
+                uint32_t inner = 0;
+                for (int i = 0; i < ni; i++) inner += d.bin[it[i]].left != BIN_LEAF;
+                first_child[k + 1] = inner;
+            }
+        }, 1u << 12);
+        for (size_t k = 0; k < cnt; k++) first_child[k + 1] += first_child[k];
+        next.assign(first_child[cnt], 0);
+        parallel_for(cnt, [&](size_t a, size_t e) {
+            for (size_t k = a; k < e; k++) {
+                uint32_t *wn = out.wnodes.data() + (base + k) * 32;
+                const uint32_t *it = items.data() + k * WIDE_K;
+                uint32_t child = first_child[k];
+                for (int i = 0; i < (int)WIDE_K; i++) {
+                    uint32_t *o = wn + 4 * i;
+                    if (i >= nitems[k]) { o[0] = o[1] = o[2] = 0x0000FFFFu; o[3] = WIDE_EMPTY; continue; }
+                    const BinNode &c = d.bin[it[i]];
+                    for (int ax = 0; ax < 3; ax++) o[ax] = (uint32_t)c.lo[ax] | (uint32_t)c.hi[ax] << 16;
+                    if (c.left == BIN_LEAF) o[3] = WIDE_LEAF | c.right;
+                    else { o[3] = (uint32_t)(base + cnt + child); next[child++] = it[i]; }
+                }
+            }
+        }, 1u << 12);
+        base += cnt;
+        level.swap(next);
+        depth++;
+    }
+    out.nwide = base;
+    out.depth = depth;
+    return 0;
+}
+
 int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, WideTree &out, std::string &err, int topology)
 {
     const bool timing = getenv("CHROMA_TIMING") != nullptr;
@@ -644,6 +811,13 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
     phase("reference test order");
     out.tri_to_dev.assign(ntriangles, 0xFFFFFFFFu);
     out.dev_to_tri.clear();
+    // (PLOC starts from the reference tree's leaf layer: its last ntriangles nodes, one leaf per triangle in Morton order --
+    //  a tree that does not end that way keeps the top-down builder)
+    if (topology == WIDE_TOPOLOGY_PLOC && (nnodes < ntriangles || ntriangles == 0)) topology = WIDE_TOPOLOGY_SAH;
+    if (timing) fprintf(stderr, "[build_wide_tree] topology %d, layered %d, %zu layers, last layer [%zu, %zu)\n", topology, (int)layered, nlayers, layer_start[nlayers - 1], layer_start[nlayers]);
+    if (topology == WIDE_TOPOLOGY_PLOC) {
+        if (ploc_topology(nodes, nnodes - ntriangles, nnodes, ntriangles, out, err) != 0) return -1;
+    } else
     if (topology == WIDE_TOPOLOGY_SAH || topology == WIDE_TOPOLOGY_SAH_GREEDY) {
         if (sah_topology(nodes, ntriangles, leaf_node, out, err, topology == WIDE_TOPOLOGY_SAH) != 0) return -1;
     } else {
@@ -810,6 +984,7 @@ int wide_topology_from_env()
     const char *e = getenv("CHROMA_TREE");
     if (e && !strcmp(e, "collapse")) return WIDE_TOPOLOGY_COLLAPSE;
     if (e && !strcmp(e, "greedy")) return WIDE_TOPOLOGY_SAH_GREEDY;
+    if (e && !strcmp(e, "ploc")) return WIDE_TOPOLOGY_PLOC;
     return WIDE_TOPOLOGY_SAH;
 }
 

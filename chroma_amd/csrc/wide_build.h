@@ -11,7 +11,10 @@ enum : uint32_t { WIDE_K = 8, WIDE_LEAF = 0x80000000u, WIDE_EMPTY = 0xFFFFFFFFu 
 // how the hierarchy above the reference's leaf boxes is chosen
 enum { WIDE_TOPOLOGY_COLLAPSE = 0,     // the reference tree with children pulled up until a node has eight
        WIDE_TOPOLOGY_SAH = 1,          // rebuilt with surface-area-heuristic splits, binary tree collapsed to wide nodes at the least total area (default)
-       WIDE_TOPOLOGY_SAH_GREEDY = 2 }; // the same splits, a wide node = a set split greedily until it has eight parts (round 1)
+       WIDE_TOPOLOGY_SAH_GREEDY = 2,   // the same splits, a wide node = a set split greedily until it has eight parts (round 1)
+       WIDE_TOPOLOGY_PLOC = 3 };       // bottom-up: parallel locally-ordered clustering of the Morton-ordered leaves (Meister & Bittner 2018), then the
+                                       // same least-area collapse; breadth-first node order.  The algorithm the DEVICE builder runs (csrc/wide_device.hip):
+                                       // this is its host twin, bit-identical by construction
 
 struct WideTree {
     std::vector<uint32_t> wnodes;       // nwide * 8 entries of 4 words: x, y, z boxes, w = child (see above)
@@ -32,7 +35,9 @@ uint32_t wide_stack_need(const uint32_t *wnodes, size_t nwide);
 // Index checks of a wide tree and its record maps (see wide_build.cpp).  Returns 0, or -1 with `err` set.
 int validate_wide_tree(const uint32_t *wnodes, size_t nwide, const uint32_t *tri_to_dev, uint32_t ntriangles,
                        const uint32_t *dev_to_tri, size_t nrecords, std::string &err);
-// CHROMA_TREE=collapse|greedy|sah (default sah)
+// CHROMA_TREE=collapse|greedy|sah|ploc (default sah)
 int wide_topology_from_env();
+// search radius of the PLOC nearest-neighbour step (clusters to either side in Morton order)
+enum { PLOC_RADIUS = 16 };
 
 }  // namespace chroma_host
