@@ -813,7 +813,20 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
     out.dev_to_tri.clear();
     // (PLOC starts from the reference tree's leaf layer: its last ntriangles nodes, one leaf per triangle in Morton order --
     //  a tree that does not end that way keeps the top-down builder)
-    if (topology == WIDE_TOPOLOGY_PLOC && (nnodes < ntriangles || ntriangles == 0)) topology = WIDE_TOPOLOGY_SAH;
+    if (topology == WIDE_TOPOLOGY_PLOC) {
+        bool leaf_layer = nnodes >= ntriangles && ntriangles > 0;
+        if (leaf_layer) {
+            std::atomic<int> not_leaf(0);
+            parallel_for(ntriangles, [&](size_t a, size_t b) {
+                for (size_t i = a; i < b; i++) {
+                    const uint32_t w = nodes[4 * (nnodes - ntriangles + i) + 3];
+                    if ((w >> NCHILD_SHIFT) != 0 || (w & CHILD_MASK) >= ntriangles || leaf_node[w & CHILD_MASK] == 0xFFFFFFFFu) { not_leaf = 1; return; }
+                }
+            });
+            leaf_layer = !not_leaf;
+        }
+        if (!leaf_layer) topology = WIDE_TOPOLOGY_SAH;
+    }
     if (timing) fprintf(stderr, "[build_wide_tree] topology %d, layered %d, %zu layers, last layer [%zu, %zu)\n", topology, (int)layered, nlayers, layer_start[nlayers - 1], layer_start[nlayers]);
     if (topology == WIDE_TOPOLOGY_PLOC) {
         if (ploc_topology(nodes, nnodes - ntriangles, nnodes, ntriangles, out, err) != 0) return -1;

@@ -36,7 +36,7 @@ def _wide(nodes, ntriangles, topology):
             os.environ['CHROMA_TREE'] = old
 
 
-@pytest.fixture(scope='module', params=['cube-collapse', 'cube-sah', 'cube-greedy', 'tiny-collapse', 'tiny-sah', 'tiny-greedy'])
+@pytest.fixture(scope='module', params=['cube-collapse', 'cube-sah', 'cube-greedy', 'cube-ploc', 'tiny-collapse', 'tiny-sah', 'tiny-greedy', 'tiny-ploc'])
 def built(request):
     want, topology = request.param.split('-')
     for name, g in _geometries():
@@ -135,7 +135,7 @@ def test_unlayered_and_overwide_trees():
     nodes.append(node(70, 72, tri, 0)); tri += 1
     nodes.append(node(75, 79, tri, 0)); tri += 1
     ref = np.array(nodes, dtype=np.uint32)
-    for topology in ('sah', 'greedy', 'collapse'):
+    for topology in ('sah', 'greedy', 'collapse', 'ploc'):          # (ploc: not a tree that ends in its leaf layer -> the top-down builder)
         w = _wide(ref, tri, topology)
         ent = w['wnodes'].reshape(-1, 4)
         leaf = ent[(ent[:, 3] & LEAF != 0) & (ent[:, 3] != EMPTY)]
@@ -162,7 +162,7 @@ def test_build_is_repeatable():
         if name != 'tiny':
             continue
         nodes = np.ascontiguousarray(g.bvh.nodes)
-        for topology in ('sah', 'greedy', 'collapse'):
+        for topology in ('sah', 'greedy', 'collapse', 'ploc'):
             a = _wide(nodes, len(g.mesh.triangles), topology)
             b = _wide(nodes, len(g.mesh.triangles), topology)
             for key in ('wnodes', 'tri_to_record', 'record_to_tri', 'rank'):
@@ -210,6 +210,37 @@ def test_index_checks_reject_a_tampered_tree():
         short = tampered()
         short['record_to_tri'] = short['record_to_tri'][:-1]
         assert not _lib.wide_validate(short, ntri)
+
+
+def test_ploc_tree_is_independent_of_the_thread_count_and_close_to_the_sah_tree():
+    """The bottom-up topology (CHROMA_TREE=ploc: the algorithm the device builder runs) is a pure function of the
+    reference tree's leaf layer -- same nodes with 1 thread and with all of them -- and its surface-area sum stays within
+    10 % of the top-down SAH tree's (measured: +6 % on tiny, +5 % on C2-lite; the collapsed reference tree: +38 %)."""
+    for name, g in _geometries():
+        if name != 'tiny':
+            continue
+        nodes = np.ascontiguousarray(g.bvh.nodes)
+        nt = len(g.mesh.triangles)
+        a = _wide(nodes, nt, 'ploc')
+        old = os.environ.get('CHROMA_HOST_THREADS')
+        os.environ['CHROMA_HOST_THREADS'] = '1'
+        try:
+            b = _wide(nodes, nt, 'ploc')
+        finally:
+            if old is None:
+                del os.environ['CHROMA_HOST_THREADS']
+            else:
+                os.environ['CHROMA_HOST_THREADS'] = old
+        for key in ('wnodes', 'tri_to_record', 'record_to_tri', 'rank'):
+            assert np.array_equal(a[key], b[key]), key
+        assert _lib.wide_validate(a, nt)
+        sah, collapse = _wide(nodes, nt, 'sah'), _wide(nodes, nt, 'collapse')
+        assert _node_area_sum(a['wnodes']) < 1.10 * _node_area_sum(sah['wnodes'])
+        assert _node_area_sum(a['wnodes']) < 0.85 * _node_area_sum(collapse['wnodes'])
+        # breadth-first numbering: the children of a node follow all nodes of its level
+        ent = a['wnodes'].reshape(-1, 4)
+        inner = ent[((ent[:, 3] & LEAF) == 0) & (ent[:, 3] != EMPTY), 3]
+        assert np.array_equal(inner, np.arange(1, len(inner) + 1))
 
 
 def _node_area_sum(wnodes):
