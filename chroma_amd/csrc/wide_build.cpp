@@ -554,8 +554,11 @@ static int sah_topology(const uint32_t *ref, uint32_t ntriangles, const std::vec
 // the order of the reference tree's last layer -- each look PLOC_RADIUS places to either side for the neighbour whose
 // union with them has the least area (ties: the lower index); two clusters that chose each other merge into a binary
 // node that takes the place of the lower one; repeat until one cluster is left.  Every step is a data-parallel pass
-// over an array, which is why the device builder (csrc/wide_device.hip) runs exactly this; areas are integers, node
-// numbers come from prefix counts, so host and device give the same tree bit for bit.  The binary tree is then cut into
+// over an array (areas are integers, node numbers are prefix counts: a device version would give the same tree bit for
+// bit), which is why this topology was built: as the host twin of a device builder.  MEASURED at C3 before writing that
+// builder (profiles/r03/ab_tree_ploc.txt): the tree has 3 % fewer node entries per ray but 6 % more triangle tests, and a
+// step takes 3.5 % longer than with the top-down SAH tree (radius 32: 3.3 %) -- so it stays an option
+// (CHROMA_TREE=ploc), and a device builder has to be the binned top-down one.  The binary tree is then cut into
 // eight-wide nodes by the same least-area dynamic programme as the SAH topology, and the wide nodes are numbered
 // breadth first (a level's nodes in the order of their parents' entries).
 struct PlocCluster { uint16_t lo[3], hi[3]; uint32_t node; };

@@ -13,8 +13,8 @@ enum { WIDE_TOPOLOGY_COLLAPSE = 0,     // the reference tree with children pulle
        WIDE_TOPOLOGY_SAH = 1,          // rebuilt with surface-area-heuristic splits, binary tree collapsed to wide nodes at the least total area (default)
        WIDE_TOPOLOGY_SAH_GREEDY = 2,   // the same splits, a wide node = a set split greedily until it has eight parts (round 1)
        WIDE_TOPOLOGY_PLOC = 3 };       // bottom-up: parallel locally-ordered clustering of the Morton-ordered leaves (Meister & Bittner 2018), then the
-                                       // same least-area collapse; breadth-first node order.  The algorithm the DEVICE builder runs (csrc/wide_device.hip):
-                                       // this is its host twin, bit-identical by construction
+                                       // same least-area collapse; breadth-first node order.  Every step is a data-parallel pass over an array -- the
+                                       // shape a DEVICE builder would take -- but the tree is 3.5 % slower to walk at C3 (profiles/r03/ab_tree_ploc.txt): not the default
 
 struct WideTree {
     std::vector<uint32_t> wnodes;       // nwide * 8 entries of 4 words: x, y, z boxes, w = child (see above)

@@ -213,7 +213,7 @@ def test_index_checks_reject_a_tampered_tree():
 
 
 def test_ploc_tree_is_independent_of_the_thread_count_and_close_to_the_sah_tree():
-    """The bottom-up topology (CHROMA_TREE=ploc: the algorithm the device builder runs) is a pure function of the
+    """The bottom-up topology (CHROMA_TREE=ploc: data-parallel passes only, the shape a device builder would take) is a pure function of the
     reference tree's leaf layer -- same nodes with 1 thread and with all of them -- and its surface-area sum stays within
     10 % of the top-down SAH tree's (measured: +6 % on tiny, +5 % on C2-lite; the collapsed reference tree: +38 %)."""
     for name, g in _geometries():
