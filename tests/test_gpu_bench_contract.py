@@ -40,6 +40,7 @@ def test_bench_line_carries_the_contract():
     assert abs(r['algorithmic_bytes_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e9 - r['achieved']) < 1e-6 * r['achieved']
     # the exact walk's rate on the same batch, and which reduction path the run took
     assert 0 < j['config']['exact_walk_photons_per_s'] < j['value'] and j['config']['reduction'].startswith('none')
+    assert j['config']['generation_order_photons_per_s'] > 0 and 'argsort_direction' in j['config']['inputs']
     c = j['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['unit'] == 'photons/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']
 
