@@ -423,7 +423,8 @@ def main():
     # ---- the exact walk's rate (one extra UNTIMED-for-the-headline batch): the reference's own traversal loop for every
     # ray (chroma_set_walk LITERAL, GPUPhotons.propagate(exact=True)) on the same batch, same step definition
     exact_rate = None
-    if rank == 0 and not os.environ.get('CHROMA_BENCH_NO_EXACT') and os.environ.get('CHROMA_WALK', 'quad') == 'quad':
+    # (single-GPU runs only: run_step holds the all-reduce of the per-channel arrays, a collective EVERY rank would have to enter)
+    if world == 1 and not os.environ.get('CHROMA_BENCH_NO_EXACT') and os.environ.get('CHROMA_WALK', 'quad') == 'quad':
         ctx.set_walk('literal')
         try:
             b = batch_for(0) if not resident else buffers[0].fill(20_000)
@@ -460,7 +461,7 @@ def main():
 
     # ---- the same batch with its photons in GENERATION order (round 2's input; one extra batch, not part of `value`)
     unsorted_rate = None
-    if rank == 0 and SORT_DIRECTIONS and not os.environ.get('CHROMA_BENCH_NO_EXACT'):
+    if world == 1 and SORT_DIRECTIONS and not os.environ.get('CHROMA_BENCH_NO_EXACT'):
         b = buffers[0]
         b.id_base = (20_001 * world + rank) * nphotons
         pos = (ctypes.c_float * 3)(0.0, 0.0, 0.0)

@@ -3432,7 +3432,9 @@ int chroma_malloc(chroma_ctx *ctx, size_t nbytes, void **d_ptr)
     std::lock_guard<std::mutex> lock(ctx->pool_mu);
     auto range = ctx->pool.equal_range(size);
     for (auto it = range.first; it != range.second; ++it) {
-        if (hipEventQuery(it->second.ev) != hipSuccess) continue;          // still in use by queued work
+        // (still in use by queued work: hipErrorNotReady is not an error here, and must not stay behind as the thread's
+        //  "last error" for the next hipGetLastError() after a kernel launch to find)
+        if (hipEventQuery(it->second.ev) != hipSuccess) { (void)hipGetLastError(); continue; }
         *d_ptr = it->second.ptr;
         ctx->pool_events.push_back(it->second.ev);
         ctx->pool.erase(it);
@@ -3441,7 +3443,6 @@ int chroma_malloc(chroma_ctx *ctx, size_t nbytes, void **d_ptr)
         ctx->pool_hits++;
         return CHROMA_OK;
     }
-    (void)hipGetLastError();                                               // (hipEventQuery's hipErrorNotReady is not an error)
     hipError_t e = hipMalloc(d_ptr, size);
     if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {
         (void)hipGetLastError();
