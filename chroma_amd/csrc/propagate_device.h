@@ -532,7 +532,10 @@ __device__ inline void rayleigh_scatter(Photon &p, cm_rng &rng)
 // all use the default model (GeoView::plain_optics, decided once at chroma_geometry_create): the bulk
 // re-emission, thin-film, wavelength-shifter and dichroic code is not compiled in, which halves the
 // registers of the per-step physics kernel for the detectors of configs C1-C4.
-template <bool FULL>
+// DEFER_SCATTER (k_physics_deal): when the photon scatters, stop after moving it to the scattering point and return
+// CMD_SCATTER -- the caller runs rayleigh_scatter (and sets the flag, forgets the triangle) later, among photons that all do.
+#define CMD_SCATTER 3
+template <bool FULL, bool DEFER_SCATTER = false>
 __device__ inline int propagate_to_boundary(Photon &p, State &s, cm_rng &rng, const GeoView &g,
                                             bool use_weights, int scatter_first)
 {
@@ -613,6 +616,7 @@ __device__ inline int propagate_to_boundary(Photon &p, State &s, cm_rng &rng, co
                 p.weight *= cm_expf(-scattering_distance / s.absorption_length);
             p.time += scattering_distance / (CM_SPEED_OF_LIGHT / s.refractive_index1);
             p.position = p.position + scattering_distance * p.direction;
+            if (DEFER_SCATTER) return CMD_SCATTER;
             rayleigh_scatter(p, rng);
             p.history |= CHROMA_RAYLEIGH_SCATTER;
             p.last_hit_triangle = -1;
