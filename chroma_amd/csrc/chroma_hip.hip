@@ -2261,8 +2261,11 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
 // kind.  Same functions, same arguments, same draws in the same order (the generator is re-seeded from the photon's draw
 // counter after the move: one Philox block): the results are k_physics<false>'s bit for bit; only the ORDER in which a
 // block appends its survivors changes, which nothing depends on.
+// RESULT (profiles/r03/ab_physics_deal.txt, C3): 0.072-0.073 s per 3 steps outside the ray cast with the deal (512-thread
+// blocks; 256: 0.070; 1024: 0.091) against 0.070-0.071 s for k_physics<false> -- the exchange (23 LDS words each way, three
+// more barriers, one more Philox block) costs what the purer waves save.  Off by default; kept as a build option.
 #ifndef PHYS_DEAL
-#define PHYS_DEAL 1
+#define PHYS_DEAL 0       // MEASURED (profiles/r03/ab_physics_deal.txt): parity-green, and no faster -- see below
 #endif
 #ifndef PHYS_DEAL_BLOCK
 #define PHYS_DEAL_BLOCK 512
