@@ -142,6 +142,10 @@ struct chroma_geometry {
     size_t device_bytes = 0;
 };
 
+// hipMalloc for the library's own working buffers: when the device is out of memory, everything parked in the pool
+// behind chroma_malloc / chroma_free is given back first (defined next to the pool)
+static hipError_t ctx_malloc(chroma_ctx *ctx, void **ptr, size_t bytes);
+
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
@@ -3198,11 +3202,11 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     const bool wide = !pair && !coop && !quad && ctx->wide_walk != CHROMA_WALK_REFERENCE && have_wide && geom->wide_stack_need <= WIDE_STACK + WIDE_SPILL;
     if (wide && !ctx->wide_spill) {
         HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipMalloc((void **)&ctx->wide_spill, (size_t)ctx->wide_waves * WIDE_SPILL * PROP_BLOCK * sizeof(uint2)));
+        HIP_TRY(ctx_malloc(ctx, (void **)&ctx->wide_spill, (size_t)ctx->wide_waves * WIDE_SPILL * PROP_BLOCK * sizeof(uint2)));
     }
     if ((coop || quad || pair) && !ctx->coop_spill) {
         HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, spill_entries(ctx) * sizeof(uint2)));
+        HIP_TRY(ctx_malloc(ctx, (void **)&ctx->coop_spill, spill_entries(ctx) * sizeof(uint2)));
     }
     // persistent ray cast: enough waves to fill the chip, each pulling rays from the queue
     unsigned waves = pair ? (unsigned)std::min<long long>((n_upper + 31) / 32, (long long)ctx->pair_waves)
@@ -3318,7 +3322,7 @@ static int launch_tail(chroma_ctx *ctx, chroma_geometry *geom, PhotonView pv, lo
         return CHROMA_OK;
     if (!ctx->coop_spill) {
         HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, spill_entries(ctx) * sizeof(uint2)));
+        HIP_TRY(ctx_malloc(ctx, (void **)&ctx->coop_spill, spill_entries(ctx) * sizeof(uint2)));
     }
     unsigned waves = (unsigned)std::min<long long>((n_upper + 7) / 8, (long long)ctx->coop_waves);
     if ((long long)waves * 8 < n_upper) return CHROMA_OK;          // (cannot happen below 8192 photons)
@@ -3344,7 +3348,7 @@ static int upload(chroma_geometry *g, const T *host, size_t count, const T **dev
     *dev_out = nullptr;
     size_t bytes = std::max(count, (size_t)1) * sizeof(T);
     void *d = nullptr;
-    HIP_TRY(hipMalloc(&d, bytes));
+    HIP_TRY(ctx_malloc(g->ctx, &d, bytes));
     g->allocations.push_back(d);
     g->device_bytes += bytes;
     if (count && host) HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
@@ -3626,6 +3630,17 @@ static void pool_release_all(chroma_ctx *ctx)       // (pool_mu held)
     for (auto &kv : ctx->pool) { hipEventSynchronize(kv.second.ev); hipFree(kv.second.ptr); ctx->pool_events.push_back(kv.second.ev); }
     ctx->pool.clear();
     ctx->pool_bytes = 0;
+}
+
+static hipError_t ctx_malloc(chroma_ctx *ctx, void **ptr, size_t bytes)
+{
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lock(ctx->pool_mu);
+        if (!ctx->pool.empty()) { pool_release_all(ctx); e = hipMalloc(ptr, bytes); }
+    }
+    return e;
 }
 
 int chroma_malloc(chroma_ctx *ctx, size_t nbytes, void **d_ptr)
@@ -4211,7 +4226,7 @@ static int distance_to_mesh_fast(chroma_ctx *ctx, chroma_geometry *geom, int32_t
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_queues(ctx, (size_t)n); if (rc) return rc;
     if (!ctx->coop_spill)
-        HIP_TRY(hipMalloc((void **)&ctx->coop_spill, spill_entries(ctx) * sizeof(uint2)));
+        HIP_TRY(ctx_malloc(ctx, (void **)&ctx->coop_spill, spill_entries(ctx) * sizeof(uint2)));
     StepState *st = ctx->d_step;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_step_set, dim3(1), dim3(1), 0, ctx->stream, st, (uint32_t)n);
@@ -4256,19 +4271,19 @@ static int ensure_queues(chroma_ctx *ctx, size_t n)
     ctx->rays = nullptr;
     ctx->rays_b = nullptr;
     ctx->queue_capacity = 0;
-    HIP_TRY(hipMalloc((void **)&ctx->queue_a, (n + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&ctx->queue_b, (n + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&ctx->hit_triangle, (n + 1) * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void **)&ctx->hit_distance, (n + 1) * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&ctx->retry_list, (n + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&ctx->rays, (n + 1) * 4 * sizeof(float4)));
-    HIP_TRY(hipMalloc((void **)&ctx->rays_b, (n + 1) * 4 * sizeof(float4)));
-    HIP_TRY(hipMalloc((void **)&ctx->work_a, (n + 1) * 4 * sizeof(float4)));
-    HIP_TRY(hipMalloc((void **)&ctx->work_b, (n + 1) * 4 * sizeof(float4)));
+    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->queue_a, (n + 1) * sizeof(uint32_t)));
+    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->queue_b, (n + 1) * sizeof(uint32_t)));
+    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->hit_triangle, (n + 1) * sizeof(int32_t)));
+    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->hit_distance, (n + 1) * sizeof(float)));
+    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->retry_list, (n + 1) * sizeof(uint32_t)));
+    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->rays, (n + 1) * 4 * sizeof(float4)));
+    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->rays_b, (n + 1) * 4 * sizeof(float4)));
+    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->work_a, (n + 1) * 4 * sizeof(float4)));
+    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->work_b, (n + 1) * 4 * sizeof(float4)));
 #if PHYS_ENDED_AOS
     if (ctx->final_rec) hipFree(ctx->final_rec);
     ctx->final_rec = nullptr;
-    HIP_TRY(hipMalloc((void **)&ctx->final_rec, (n + 1) * 4 * sizeof(float4)));
+    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->final_rec, (n + 1) * 4 * sizeof(float4)));
     HIP_TRY(hipMemset(ctx->final_rec, 0, (n + 1) * 4 * sizeof(float4)));
     ctx->final_epoch = 0;
 #endif
