@@ -303,6 +303,37 @@ def test_simulation_batching_and_per_event_split(gpu, tiny_geometry):
         assert (ev.flat_hits.flags & event.SURFACE_DETECT != 0).all()
 
 
+def test_simulation_exact_switch_and_per_event_hits(gpu, oracle_mod, tiny_geometry):
+    """Simulation(exact=True) propagates with the reference's own traversal loop for every ray (the walk 'literal') and
+    leaves the context's walk as it was; on photons without erratic hits it gives what the default walk gives, photon
+    for photon.  The events' hits come from ONE sort of the batch's hits by event index: the same hits, event by event,
+    as masking the batch once per event (chroma/sim.py:118-121)."""
+    from chroma_amd.sim import Simulation
+
+    def events():
+        return [oracle_mod.generate_bomb(n, seed=300 + n) for n in (9000, 15000, 4000)]
+    results = {}
+    for exact in (False, True):
+        sim = Simulation(tiny_geometry, geant4_processes=0, seed=11, exact=exact)
+        assert gpu.get_context().walk == 'quad'
+        results[exact] = list(sim.simulate(events(), keep_photons_end=True, photons_per_batch=40000, max_steps=100))
+        assert gpu.get_context().walk == 'quad'
+    for a, b in zip(results[False], results[True]):
+        assert_bit_exact(a.photons_end, b.photons_end, 'Simulation exact vs default, event %d' % a.id)
+        assert len(a.flat_hits) == len(b.flat_hits) > 0
+    # one batch, three events: each event's hits are exactly the detected photons of ITS photons_end that sit on a channel
+    for ev in results[False]:
+        end = ev.photons_end
+        det = (end.flags & event.SURFACE_DETECT) != 0
+        tri = end.last_hit_triangles
+        chan = np.full(len(end), -1, dtype=np.int64)
+        ok = det & (tri > -1)
+        chan[ok] = tiny_geometry.solid_id_to_channel_index[tiny_geometry.solid_id[tri[ok]]]
+        want_t = np.sort(end.t[chan >= 0])
+        assert np.array_equal(np.sort(ev.flat_hits.t), want_t)
+        assert (ev.flat_hits.evidx == ev.id).all()
+
+
 def test_daq_matches_oracle_and_reference_test(gpu, oracle_mod, tiny_geometry, tiny_packed):
     """GPUDaq (chroma/gpu/daq.py + cuda/daq.cu) against the oracle's run_daq, bit for bit, and the
     intent of the reference's test/test_detector.py (time spread 1.2 ns, unit charge +- 0.1)."""
