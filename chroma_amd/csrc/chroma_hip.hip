@@ -307,8 +307,8 @@ __device__ inline int make_ray_record(const GeoView &g, float4 *r, v3 origin, v3
         if (!moderate) {
             status = HIT_RETRY;
         } else {
-            a = ray_fast(g, noid, inv_dir).a;
-            // b exactly as ray_fast forms it (blo = b - a, bhi = b + a are rebuilt by the kernels)
+            a = ray_fast(g, noid, inv_dir, 1.0f).a;
+            // b exactly as ray_fast forms it (blo = b - G a, bhi = b + G a are rebuilt by the kernels; G travels in r[2].w)
             b = mk3(cm_fmaf(g.world_origin[0], inv_dir.x, noid.x), cm_fmaf(g.world_origin[1], inv_dir.y, noid.y),
                     cm_fmaf(g.world_origin[2], inv_dir.z, noid.z));
             status = 0;
@@ -316,7 +316,7 @@ __device__ inline int make_ray_record(const GeoView &g, float4 *r, v3 origin, v3
     }
     r[0] = make_float4(origin.x, origin.y, origin.z, __int_as_float(last_hit));
     r[1] = make_float4(direction.x, direction.y, direction.z, __int_as_float(status));
-    r[2] = make_float4(a.x, a.y, a.z, 0.0f);
+    r[2] = make_float4(a.x, a.y, a.z, ray_growth(g, origin));
     r[3] = make_float4(b.x, b.y, b.z, 0.0f);
     return status;
 }
@@ -406,8 +406,8 @@ k_raycast_persistent(GeoView g, const float4 *rays, int first_photon, StepState 
                         last_hit = __float_as_int(r0.w);
                         rf.a = mk3(r2.x, r2.y, r2.z);
                         const v3 bb = mk3(r3.x, r3.y, r3.z);
-                        rf.blo = bb - rf.a;
-                        rf.bhi = bb + rf.a;
+                        rf.blo = bb - r2.w * rf.a;
+                        rf.bhi = bb + r2.w * rf.a;
                         triangle_index = -1;
                         min_distance = -1.0f;
                         sp = 0;
@@ -597,8 +597,8 @@ k_raycast_wide(GeoView g, const float4 *rays, int first_photon, StepState *st,
                         last_hit = __float_as_int(r0.w);
                         rf.a = mk3(r2.x, r2.y, r2.z);
                         const v3 bb = mk3(r3.x, r3.y, r3.z);
-                        rf.blo = bb - rf.a;
-                        rf.bhi = bb + rf.a;
+                        rf.blo = bb - r2.w * rf.a;
+                        rf.bhi = bb + r2.w * rf.a;
                         triangle_index = -1;
                         min_distance = -1.0f;
                         sp = 0;
@@ -820,8 +820,8 @@ k_raycast_coop(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     last_hit = __float_as_int(r0.w);
                     rf.a = mk3(r2.x, r2.y, r2.z);
                     const v3 bb = mk3(r3.x, r3.y, r3.z);
-                    rf.blo = bb - rf.a;
-                    rf.bhi = bb + rf.a;
+                    rf.blo = bb - r2.w * rf.a;
+                    rf.bhi = bb + r2.w * rf.a;
                     triangle_index = -1;
                     min_distance = -1.0f;
                     sp = 0;
@@ -1112,7 +1112,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     if (j == 0) { ray_od[0] = r0.x; ray_od[1] = r0.y; ray_od[2] = r0.z; ray_od[3] = r1.x; ray_od[4] = r1.y; ray_od[5] = r1.z; }
                     { const int lh = __float_as_int(r0.w); last_hit_w = lh >= 0 ? (0x80000000u | (uint32_t)lh) : WIDE_NONE; }
                     rax = r2.x; ray_ = r2.y; raz = r2.z;
-                    { const float mx = cm_fabsf(rax), my = cm_fabsf(ray_), mz = cm_fabsf(raz);
+                    { const float mx = r2.w * cm_fabsf(rax), my = r2.w * cm_fabsf(ray_), mz = r2.w * cm_fabsf(raz);       // (growth of the boxes: ray_growth)
                       rbx = (f32x2){r3.x - mx, r3.x + mx}; rby = (f32x2){r3.y - my, r3.y + my}; rbz = (f32x2){r3.z - mz, r3.z + mz}; }
                     rsx = rax < 0.f ? 16u : 0u; rsy = ray_ < 0.f ? 16u : 0u; rsz = raz < 0.f ? 16u : 0u;
                     triangle_index = -1;
@@ -1408,9 +1408,9 @@ k_raycast_pair(GeoView g, const float4 *rays, int first_photon, StepState *st,
                     direction = mk3(r1.x, r1.y, r1.z);
                     { const int lh = __float_as_int(r0.w); last_hit_w = lh >= 0 ? (0x80000000u | (uint32_t)lh) : WIDE_NONE; }
                     rax = r2.x; ray_ = r2.y; raz = r2.z;
-                    rbx = (f32x2){r3.x - rax, r3.x + rax};
-                    rby = (f32x2){r3.y - ray_, r3.y + ray_};
-                    rbz = (f32x2){r3.z - raz, r3.z + raz};
+                    rbx = (f32x2){r3.x - r2.w * rax, r3.x + r2.w * rax};
+                    rby = (f32x2){r3.y - r2.w * ray_, r3.y + r2.w * ray_};
+                    rbz = (f32x2){r3.z - r2.w * raz, r3.z + r2.w * raz};
                     triangle_index = -1;
                     min_distance = -1.0f;
                     prune_t = cm_inff();
@@ -1670,7 +1670,7 @@ k_raycast_packet(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tria
                 ox = r0.x; oy = r0.y; oz = r0.z; dx = r1.x; dy = r1.y; dz = r1.z;
                 last_hit = __float_as_int(r0.w);
                 rax = r2.x; ray_ = r2.y; raz = r2.z;
-                const float mx = cm_fabsf(rax), my = cm_fabsf(ray_), mz = cm_fabsf(raz);
+                const float mx = r2.w * cm_fabsf(rax), my = r2.w * cm_fabsf(ray_), mz = r2.w * cm_fabsf(raz);
                 rbx = (f32x2){r3.x - mx, r3.x + mx}; rby = (f32x2){r3.y - my, r3.y + my}; rbz = (f32x2){r3.z - mz, r3.z + mz};
                 rsx = rax < 0.f ? 16u : 0u; rsy = ray_ < 0.f ? 16u : 0u; rsz = raz < 0.f ? 16u : 0u;
                 on = true;
@@ -1796,7 +1796,7 @@ __device__ inline int coop_cast(const GeoView &g, v3 origin, v3 direction, int l
         if (!moderate) {
             triangle_index = HIT_RETRY;
         } else {
-            rf = ray_fast(g, noid, inv_dir);
+            rf = ray_fast(g, noid, inv_dir, ray_growth(g, origin));
             cur = 0;
             active = true;
         }
@@ -3403,14 +3403,14 @@ __global__ void k_rays_from_arrays(GeoView g, int n, const float *origin_in, con
     int status = moderate ? 0 : HIT_RETRY;                 // (a NaN ray is not moderate: the literal walk answers)
     v3 a = mk3(0.f, 0.f, 0.f), b = mk3(0.f, 0.f, 0.f);
     if (moderate) {
-        a = ray_fast(g, noid, inv_dir).a;
+        a = ray_fast(g, noid, inv_dir, 1.0f).a;
         b = mk3(cm_fmaf(g.world_origin[0], inv_dir.x, noid.x), cm_fmaf(g.world_origin[1], inv_dir.y, noid.y),
                 cm_fmaf(g.world_origin[2], inv_dir.z, noid.z));
     }
     float4 *r = rays + 4 * (size_t)slot;
     r[0] = make_float4(origin.x, origin.y, origin.z, __int_as_float(last_hit));
     r[1] = make_float4(direction.x, direction.y, direction.z, __int_as_float(status));
-    r[2] = make_float4(a.x, a.y, a.z, 0.0f);
+    r[2] = make_float4(a.x, a.y, a.z, ray_growth(g, origin));
     r[3] = make_float4(b.x, b.y, b.z, 0.0f);
     if (status != 0) {
         hit_triangle[slot] = status;
@@ -4016,6 +4016,12 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
         for (int a = 0; a < 3; a++)
             maxabs = std::max(maxabs, std::max(fabsf(d->world_origin[a]), fabsf(d->world_origin[a] + 65535.0f * d->world_scale)));
         v.suspect_margin = 2e-6f * maxabs;
+        // growth of the boxes in the fast slab test (ray_growth, propagate_device.h): four times the bound on what the fused
+        // evaluation can differ from the reference's, at least a quarter of a quantum, at most the whole quantum of rounds 1-2
+        // (CHROMA_SLAB_GROW overrides: A/B runs)
+        const double bound = ldexp(1.0, -24) * (10.0 * 65534.0 + 2.0 * (double)maxabs / std::max((double)d->world_scale, 1e-30));
+        v.slab_grow = (float)std::min(1.0, std::max(0.25, 4.0 * bound));
+        if (const char *e = getenv("CHROMA_SLAB_GROW")) v.slab_grow = (float)std::min(1.0, std::max(0.0625, atof(e)));
     }
     v.wavelength_n = d->wavelength_n; v.wavelength_start = d->wavelength_start; v.wavelength_step = d->wavelength_step;
     v.time_n = d->time_n; v.time_start = d->time_start; v.time_step = d->time_step;

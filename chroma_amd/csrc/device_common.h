@@ -78,6 +78,7 @@ struct GeoView {
     float world_origin[3];
     float world_scale;
     float suspect_margin;            // see record_hit_is_regular (propagate_device.h)
+    float slab_grow;                 // quanta by which the fast slab test grows a box on every side (ray_growth, propagate_device.h)
     uint32_t wavelength_n; float wavelength_start, wavelength_step;
     uint32_t time_n;       float time_start, time_step;
     uint32_t nnodes, ntriangles, nsolids, nchannels, nwide;

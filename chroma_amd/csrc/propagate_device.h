@@ -241,23 +241,39 @@ struct TravStack {
 #define TRAV_LDS_WORDS(LDS_N, BLOCK) (((LDS_N) + TRAV_PENDING) * (BLOCK))
 
 // Fast slab test used when every component of 1/d is finite and moderate (|1/d| < 1e30, i.e.
-// all rays but the exactly/nearly axis-parallel ones).  The box is the node's box grown by one
-// quantum on every side and the dequantisation is folded into two per-ray constants, so a bound
+// all rays but the exactly/nearly axis-parallel ones).  The box is the node's box grown by G quanta
+// on every side (G <= 1: ray_growth below) and the dequantisation is folded into two per-ray constants, so a bound
 // costs one convert and one fma:
-//     t = (origin_w + (q -+ 1) * scale - o) / d  =  fma(q, a, b -+ a),  a = scale/d, b = (origin_w - o)/d
+//     t = (origin_w + (q -+ G) * scale - o) / d  =  fma(q, a, b -+ G a),  a = scale/d, b = (origin_w - o)/d
 // Growing the box makes this test strictly more permissive than the reference's slab test
 // (intersect.h:107-147, whose rounding differs by far less than a quantum), so it never culls a
 // box the reference would enter: the set of triangles tested still contains the reference's.
+// HOW MUCH the box is grown (round 3).  The growth only has to cover the difference between the two evaluations of
+// the same slab distance -- the reference's fl(fl(fl(wo + fl(q ws)) I) + N) and the fused fl(fma(q, fl(ws I), fl(fl(fma(wo,
+// I, N)) -+ G |a|))) with the same I = fl(1/d) and N = fl(-o/d).  With u = 2^-24, E the extent of the 16-bit grid, Lmax the
+// largest world coordinate of a grid face and the ray's origin within 1.5 E of the grid's centre, the reference's value is
+// within u |I| (3 E + 2 Lmax) of the exact one and the fused value within u |I| 7 E, so the two differ by at most
+// u (10 E + 2 Lmax) |I| = u (10 * 65534 + 2 Lmax / ws) quanta * |a| -- 0.04 of a quantum for a world centred on the origin.
+// GeoView::slab_grow is four times that bound, at least a quarter of a quantum and at most one (chroma_geometry_create); rounds
+// 1 and 2 grew every box by a whole quantum, i.e. a triangle of ~13 quanta tested as if it were ~17 wide instead of ~15.5.
+// A ray whose origin lies farther out than 1.5 E from the centre keeps the whole quantum.
+__device__ inline float ray_growth(const GeoView &g, v3 origin)
+{
+    const float half = 32767.0f * g.world_scale, reach = 3.0f * half;         // 1.5 E
+    const bool near = cm_fabsf(origin.x - (g.world_origin[0] + half)) <= reach && cm_fabsf(origin.y - (g.world_origin[1] + half)) <= reach &&
+                      cm_fabsf(origin.z - (g.world_origin[2] + half)) <= reach;
+    return near ? g.slab_grow : 1.0f;
+}
 struct RayFast { v3 a, blo, bhi; };
-__device__ inline RayFast ray_fast(const GeoView &g, v3 noid, v3 inv_dir)
+__device__ inline RayFast ray_fast(const GeoView &g, v3 noid, v3 inv_dir, float grow)
 {
     RayFast r;
     float ws = g.world_scale;
     r.a = mk3(ws * inv_dir.x, ws * inv_dir.y, ws * inv_dir.z);
     v3 b = mk3(cm_fmaf(g.world_origin[0], inv_dir.x, noid.x), cm_fmaf(g.world_origin[1], inv_dir.y, noid.y),
                cm_fmaf(g.world_origin[2], inv_dir.z, noid.z));
-    r.blo = b - r.a;
-    r.bhi = b + r.a;
+    r.blo = b - grow * r.a;
+    r.bhi = b + grow * r.a;
     return r;
 }
 __device__ inline float box_tmin_fast(const RayFast &r, uint4 nd)
