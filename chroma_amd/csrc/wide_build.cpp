@@ -410,10 +410,9 @@ static uint32_t build_subtree_dp(Prim *prims, size_t first, size_t count, std::v
     return emit_wide(d, 0, nodes, 0, max_depth);
 }
 
-static int sah_topology(const uint32_t *ref, uint32_t ntriangles, const std::vector<uint32_t> &leaf_node, WideTree &out, std::string &err, bool collapse_dp)
+// one primitive per triangle that hangs under a reachable leaf, in triangle order (threaded: count, place)
+static void make_prims(const uint32_t *ref, uint32_t ntriangles, const std::vector<uint32_t> &leaf_node, std::vector<Prim> &prims)
 {
-    // one primitive per triangle that hangs under a reachable leaf, in triangle order (threaded: count, place)
-    std::vector<Prim> prims;
     {
         const unsigned nt = hw_threads();
         const size_t chunk = ((size_t)ntriangles + nt - 1) / nt;
@@ -441,6 +440,12 @@ static int sah_topology(const uint32_t *ref, uint32_t ntriangles, const std::vec
             }
         }, 1);
     }
+}
+
+static int sah_topology(const uint32_t *ref, uint32_t ntriangles, const std::vector<uint32_t> &leaf_node, WideTree &out, std::string &err, bool collapse_dp)
+{
+    std::vector<Prim> prims;
+    make_prims(ref, ntriangles, leaf_node, prims);
     const size_t np = prims.size();
     if (np > 0x7FFFFFFFull) { err = "wide tree: too many triangles"; return -1; }
     const size_t task_size = std::max<size_t>(1u << 16, np / (4 * (size_t)hw_threads()));
@@ -595,6 +600,71 @@ static inline void dp_fill_node(DpScratch &d, size_t n)
     }
 }
 
+// The binary tree of `d` (boxes and D(n, k) filled) cut into eight-wide nodes at the least total area, the wide nodes numbered
+// BREADTH FIRST: a level's nodes in the order of their parents' entries.  Every level is a data-parallel pass.
+static int emit_breadth_first(const DpScratch &d, uint32_t root, WideTree &out, std::string &err)
+{
+    out.wnodes.clear();
+    std::vector<uint32_t> level(1, root), next;
+    size_t base = 0;
+    uint32_t depth = 0;
+    if (d.bin[root].left == BIN_LEAF) {                          // a single triangle: one node, one leaf entry
+        out.wnodes.assign(32, 0);
+        for (int i = 0; i < (int)WIDE_K; i++) { uint32_t *o = out.wnodes.data() + 4 * i; o[0] = o[1] = o[2] = 0x0000FFFFu; o[3] = WIDE_EMPTY; }
+        const BinNode &b = d.bin[root];
+        for (int a = 0; a < 3; a++) out.wnodes[a] = (uint32_t)b.lo[a] | (uint32_t)b.hi[a] << 16;
+        out.wnodes[3] = WIDE_LEAF | b.right;
+        out.nwide = 1; out.depth = 1;
+        return 0;
+    }
+    while (!level.empty()) {
+        const size_t cnt = level.size();
+        if (base + cnt > 0x7FFFFFFFull) { err = "wide tree: more than 2^31 nodes"; return -1; }
+        out.wnodes.resize((base + cnt) * 32);
+        // entries of every node of the level, and how many inner children each has
+        std::vector<uint32_t> items(cnt * WIDE_K);
+        std::vector<uint8_t> nitems(cnt);
+        std::vector<uint32_t> first_child(cnt + 1, 0);
+        parallel_for(cnt, [&](size_t a, size_t e) {
+            for (size_t k = a; k < e; k++) {
+                const BinNode &b = d.bin[level[k]];
+                uint32_t *it = items.data() + k * WIDE_K;
+                int ni = 0;
+                const int j = d.left_share[(size_t)level[k] * 8];
+                emit_entries(d, b.left, j, it, ni);
+                emit_entries(d, b.right, (int)WIDE_K - j, it, ni);
+                nitems[k] = (uint8_t)ni;
+                uint32_t inner = 0;
+                for (int i = 0; i < ni; i++) inner += d.bin[it[i]].left != BIN_LEAF;
+                first_child[k + 1] = inner;
+            }
+        }, 1u << 12);
+        for (size_t k = 0; k < cnt; k++) first_child[k + 1] += first_child[k];
+        next.assign(first_child[cnt], 0);
+        parallel_for(cnt, [&](size_t a, size_t e) {
+            for (size_t k = a; k < e; k++) {
+                uint32_t *wn = out.wnodes.data() + (base + k) * 32;
+                const uint32_t *it = items.data() + k * WIDE_K;
+                uint32_t child = first_child[k];
+                for (int i = 0; i < (int)WIDE_K; i++) {
+                    uint32_t *o = wn + 4 * i;
+                    if (i >= nitems[k]) { o[0] = o[1] = o[2] = 0x0000FFFFu; o[3] = WIDE_EMPTY; continue; }
+                    const BinNode &c = d.bin[it[i]];
+                    for (int ax = 0; ax < 3; ax++) o[ax] = (uint32_t)c.lo[ax] | (uint32_t)c.hi[ax] << 16;
+                    if (c.left == BIN_LEAF) o[3] = WIDE_LEAF | c.right;
+                    else { o[3] = (uint32_t)(base + cnt + child); next[child++] = it[i]; }
+                }
+            }
+        }, 1u << 12);
+        base += cnt;
+        level.swap(next);
+        depth++;
+    }
+    out.nwide = base;
+    out.depth = depth;
+    return 0;
+}
+
 static int ploc_topology(const uint32_t *ref, size_t leaf_lo, size_t leaf_hi, uint32_t ntriangles, WideTree &out, std::string &err)
 {
     const size_t n = leaf_hi - leaf_lo;
@@ -656,66 +726,122 @@ static int ploc_topology(const uint32_t *ref, size_t leaf_lo, size_t leaf_hi, ui
         if (nxt.size() == m) { err = "wide tree: clustering made no progress"; return -1; }      // (cannot happen: the least pair is mutual)
         cur.swap(nxt);
     }
-    // breadth-first emission
-    out.wnodes.clear();
-    std::vector<uint32_t> level(1, cur[0].node), next;
-    size_t base = 0;
-    uint32_t depth = 0;
-    if (n == 1) {                                                // a single triangle: one node, one leaf entry
+    return emit_breadth_first(d, cur[0].node, out, err);
+}
+
+// ---- "levels": the same SAH splits with NOTHING left to the schedule -- the host twin of the device builder ------------------
+// sah_topology's tree depends on the machine a little: sets above a size that follows from the thread count become wide nodes by
+// the greedy rule, and std::partition leaves the two halves of a set in an order of its own.  The device builder
+// (csrc/wide_device.hip) cannot follow either, so the algorithm is pinned down here, once, for both:
+//   * a set of n triangles (in the order it has reached) is split in two, always: n <= 32 by the exact sweep -- stable sort
+//     by doubled centroid on each axis, least l.area * nl + r.area * nr, first minimum in the order (axis, position), the set
+//     left sorted on the winning axis; n > 32 by 32 bins on each axis that has extent, first minimum in the order (axis, bin),
+//     a STABLE partition; centroids that all coincide: the set is halved where it stands;
+//   * that all the way down to single triangles: ONE binary tree over all triangles;
+//   * boxes and the least-area table D(n, k) bottom-up over the whole tree, wide nodes emitted breadth first
+//     (emit_breadth_first): no top part, no tasks -- the threads here only share out work whose result is fixed.
+// Areas are products of 16-bit integers in doubles, costs products of those with counts: IEEE arithmetic without contraction
+// gives the device the same numbers.  Binary nodes are numbered in preorder here (a set of n triangles owns 2n-1 consecutive
+// numbers, so subtrees can be built by different threads) and by level on the device; the wide tree does not depend on it.
+static size_t split_stable(Prim *p, size_t count, std::vector<Prim> &tmp)
+{
+    if (count <= SWEEP_MAX) return split_sweep(p, count);
+    IBox cb; centroid_bounds(p, count, cb);
+    Bins b; b.clear();
+    fill_bins(p, count, cb, b);
+    int axis, bin;
+    if (!best_split(b, cb, axis, bin)) return count / 2;
+    const uint32_t cmin = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
+    if (tmp.size() < count) tmp.resize(count);
+    size_t nl = 0, nr = 0;
+    for (size_t i = 0; i < count; i++) { if (bin_of(cent2(p[i], axis), cmin, ext) <= bin) p[nl++] = p[i]; else tmp[nr++] = p[i]; }
+    memcpy(p + nl, tmp.data(), nr * sizeof(Prim));
+    return (nl == 0 || nl == count) ? count / 2 : nl;
+}
+
+static inline void bin_from_children(DpScratch &d, size_t n)
+{
+    BinNode &b = d.bin[n];
+    const BinNode &l = d.bin[b.left], &r = d.bin[b.right];
+    for (int a = 0; a < 3; a++) { b.lo[a] = std::min(l.lo[a], r.lo[a]); b.hi[a] = std::max(l.hi[a], r.hi[a]); }
+    dp_fill_node(d, n);
+}
+
+static int levels_topology(const uint32_t *ref, uint32_t ntriangles, const std::vector<uint32_t> &leaf_node, WideTree &out, std::string &err)
+{
+    std::vector<Prim> prims;
+    make_prims(ref, ntriangles, leaf_node, prims);
+    const size_t np = prims.size();
+    if (np > 0x3FFFFFFFull) { err = "wide tree: too many triangles"; return -1; }
+    if (np == 0) {
         out.wnodes.assign(32, 0);
         for (int i = 0; i < (int)WIDE_K; i++) { uint32_t *o = out.wnodes.data() + 4 * i; o[0] = o[1] = o[2] = 0x0000FFFFu; o[3] = WIDE_EMPTY; }
-        const BinNode &b = d.bin[0];
-        for (int a = 0; a < 3; a++) out.wnodes[a] = (uint32_t)b.lo[a] | (uint32_t)b.hi[a] << 16;
-        out.wnodes[3] = WIDE_LEAF | 0u;
         out.nwide = 1; out.depth = 1;
         return 0;
     }
-    while (!level.empty()) {
-        const size_t cnt = level.size();
-        if (base + cnt > 0x7FFFFFFFull) { err = "wide tree: more than 2^31 nodes"; return -1; }
-        out.wnodes.resize((base + cnt) * 32);
-        // entries of every node of the level, and how many inner children each has
-        std::vector<uint32_t> items(cnt * WIDE_K);
-        std::vector<uint8_t> nitems(cnt);
-        std::vector<uint32_t> first_child(cnt + 1, 0);
-        parallel_for(cnt, [&](size_t a, size_t e) {
-            for (size_t k = a; k < e; k++) {
-                const BinNode &b = d.bin[level[k]];
-                uint32_t *it = items.data() + k * WIDE_K;
-                int ni = 0;
-                const int j = d.left_share[(size_t)level[k] * 8];
-                emit_entries(d, b.left, j, it, ni);
-                emit_entries(d, b.right, (int)WIDE_K - j, it, ni);
-                nitems[k] = (uint8_t)ni;
-                uint32_t inner = 0;
-                for (int i = 0; i < ni; i++) inner += d.bin[it[i]].left != BIN_LEAF;
-                first_child[k + 1] = inner;
-            }
-        }, 1u << 12);
-        for (size_t k = 0; k < cnt; k++) first_child[k + 1] += first_child[k];
-        next.assign(first_child[cnt], 0);
-        parallel_for(cnt, [&](size_t a, size_t e) {
-            for (size_t k = a; k < e; k++) {
-                uint32_t *wn = out.wnodes.data() + (base + k) * 32;
-                const uint32_t *it = items.data() + k * WIDE_K;
-                uint32_t child = first_child[k];
-                for (int i = 0; i < (int)WIDE_K; i++) {
-                    uint32_t *o = wn + 4 * i;
-                    if (i >= nitems[k]) { o[0] = o[1] = o[2] = 0x0000FFFFu; o[3] = WIDE_EMPTY; continue; }
-                    const BinNode &c = d.bin[it[i]];
-                    for (int ax = 0; ax < 3; ax++) o[ax] = (uint32_t)c.lo[ax] | (uint32_t)c.hi[ax] << 16;
-                    if (c.left == BIN_LEAF) o[3] = WIDE_LEAF | c.right;
-                    else { o[3] = (uint32_t)(base + cnt + child); next[child++] = it[i]; }
-                }
-            }
-        }, 1u << 12);
-        base += cnt;
-        level.swap(next);
-        depth++;
+    DpScratch d;
+    const size_t nb = 2 * np - 1;
+    d.bin.resize(nb);
+    d.cost.assign(nb * 8, 0.0f);
+    d.left_share.assign(nb * 8, 0);
+    d.own_node.assign(nb * 8, 0);
+    struct Job { size_t first, count; uint32_t node; };
+    const size_t task_size = std::max<size_t>(1u << 16, np / (4 * (size_t)hw_threads()));      // (scheduling only)
+    std::vector<Job> stack(1, Job{0, np, 0}), tasks;
+    std::vector<uint32_t> top_nodes;
+    {
+        std::vector<Prim> tmp;
+        while (!stack.empty()) {
+            Job j = stack.back(); stack.pop_back();
+            if (j.count <= task_size) { tasks.push_back(j); continue; }
+            const size_t nl = split_parallel(prims.data(), j.first, j.count, tmp);        // (binned, stable: the same split as split_stable)
+            BinNode &b = d.bin[j.node];
+            b.left = j.node + 1; b.right = j.node + (uint32_t)(2 * nl);
+            top_nodes.push_back(j.node);
+            stack.push_back(Job{j.first + nl, j.count - nl, b.right});
+            stack.push_back(Job{j.first, nl, b.left});
+        }
     }
-    out.nwide = base;
-    out.depth = depth;
-    return 0;
+    {
+        std::atomic<size_t> next(0);
+        const size_t ntasks = tasks.size();
+        unsigned nt = (unsigned)std::min<size_t>(hw_threads(), std::max<size_t>(1, ntasks));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&] {
+                std::vector<Prim> tmp;
+                std::vector<Job> todo;
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= ntasks) break;
+                    todo.assign(1, tasks[k]);
+                    while (!todo.empty()) {
+                        Job j = todo.back(); todo.pop_back();
+                        BinNode &b = d.bin[j.node];
+                        if (j.count == 1) {
+                            const Prim &q = prims[j.first];
+                            for (int a = 0; a < 3; a++) { b.lo[a] = q.lo[a]; b.hi[a] = q.hi[a]; }
+                            b.left = BIN_LEAF; b.right = (uint32_t)j.first;
+                            continue;
+                        }
+                        const size_t nl = split_stable(prims.data() + j.first, j.count, tmp);
+                        b.left = j.node + 1; b.right = j.node + (uint32_t)(2 * nl);
+                        todo.push_back(Job{j.first + nl, j.count - nl, b.right});
+                        todo.push_back(Job{j.first, nl, b.left});
+                    }
+                    // children carry larger numbers than their parents: one backward sweep over the task's own numbers
+                    for (size_t n = (size_t)tasks[k].node + 2 * tasks[k].count - 1; n-- > (size_t)tasks[k].node;)
+                        if (d.bin[n].left != BIN_LEAF) bin_from_children(d, n);
+                }
+            });
+        for (auto &t : th) t.join();
+    }
+    std::sort(top_nodes.begin(), top_nodes.end());
+    for (size_t i = top_nodes.size(); i-- > 0;) bin_from_children(d, top_nodes[i]);
+    out.dev_to_tri.resize(np);
+    parallel_for(np, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) out.dev_to_tri[i] = prims[i].tri; });
+    { std::vector<Prim>().swap(prims); }
+    return emit_breadth_first(d, 0, out, err);
 }
 
 int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, WideTree &out, std::string &err, int topology)
@@ -833,6 +959,9 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
     if (timing) fprintf(stderr, "[build_wide_tree] topology %d, layered %d, %zu layers, last layer [%zu, %zu)\n", topology, (int)layered, nlayers, layer_start[nlayers - 1], layer_start[nlayers]);
     if (topology == WIDE_TOPOLOGY_PLOC) {
         if (ploc_topology(nodes, nnodes - ntriangles, nnodes, ntriangles, out, err) != 0) return -1;
+    } else
+    if (topology == WIDE_TOPOLOGY_LEVELS) {
+        if (levels_topology(nodes, ntriangles, leaf_node, out, err) != 0) return -1;
     } else
     if (topology == WIDE_TOPOLOGY_SAH || topology == WIDE_TOPOLOGY_SAH_GREEDY) {
         if (sah_topology(nodes, ntriangles, leaf_node, out, err, topology == WIDE_TOPOLOGY_SAH) != 0) return -1;
@@ -1001,6 +1130,7 @@ int wide_topology_from_env()
     if (e && !strcmp(e, "collapse")) return WIDE_TOPOLOGY_COLLAPSE;
     if (e && !strcmp(e, "greedy")) return WIDE_TOPOLOGY_SAH_GREEDY;
     if (e && !strcmp(e, "ploc")) return WIDE_TOPOLOGY_PLOC;
+    if (e && !strcmp(e, "levels")) return WIDE_TOPOLOGY_LEVELS;
     return WIDE_TOPOLOGY_SAH;
 }
 

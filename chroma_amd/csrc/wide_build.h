@@ -12,9 +12,12 @@ enum : uint32_t { WIDE_K = 8, WIDE_LEAF = 0x80000000u, WIDE_EMPTY = 0xFFFFFFFFu 
 enum { WIDE_TOPOLOGY_COLLAPSE = 0,     // the reference tree with children pulled up until a node has eight
        WIDE_TOPOLOGY_SAH = 1,          // rebuilt with surface-area-heuristic splits, binary tree collapsed to wide nodes at the least total area (default)
        WIDE_TOPOLOGY_SAH_GREEDY = 2,   // the same splits, a wide node = a set split greedily until it has eight parts (round 1)
-       WIDE_TOPOLOGY_PLOC = 3 };       // bottom-up: parallel locally-ordered clustering of the Morton-ordered leaves (Meister & Bittner 2018), then the
+       WIDE_TOPOLOGY_PLOC = 3,       // bottom-up: parallel locally-ordered clustering of the Morton-ordered leaves (Meister & Bittner 2018), then the
                                        // same least-area collapse; breadth-first node order.  Every step is a data-parallel pass over an array -- the
                                        // shape a DEVICE builder would take -- but the tree is 3.5 % slower to walk at C3 (profiles/r03/ab_tree_ploc.txt): not the default
+       WIDE_TOPOLOGY_LEVELS = 4 };     // the SAH splits of (1) with nothing left to the schedule: one binary tree over all triangles, stable
+                                       // partitions, the least-area collapse over the whole tree, breadth-first node order -- what the device
+                                       // builder (csrc/wide_device.hip) makes, bit for bit
 
 struct WideTree {
     std::vector<uint32_t> wnodes;       // nwide * 8 entries of 4 words: x, y, z boxes, w = child (see above)
@@ -35,7 +38,7 @@ uint32_t wide_stack_need(const uint32_t *wnodes, size_t nwide);
 // Index checks of a wide tree and its record maps (see wide_build.cpp).  Returns 0, or -1 with `err` set.
 int validate_wide_tree(const uint32_t *wnodes, size_t nwide, const uint32_t *tri_to_dev, uint32_t ntriangles,
                        const uint32_t *dev_to_tri, size_t nrecords, std::string &err);
-// CHROMA_TREE=collapse|greedy|sah|ploc (default sah)
+// CHROMA_TREE=collapse|greedy|sah|ploc|levels (default sah)
 int wide_topology_from_env();
 // search radius of the PLOC nearest-neighbour step (clusters to either side in Morton order)
 enum { PLOC_RADIUS = 16 };

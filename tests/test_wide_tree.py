@@ -36,7 +36,7 @@ def _wide(nodes, ntriangles, topology):
             os.environ['CHROMA_TREE'] = old
 
 
-@pytest.fixture(scope='module', params=['cube-collapse', 'cube-sah', 'cube-greedy', 'cube-ploc', 'tiny-collapse', 'tiny-sah', 'tiny-greedy', 'tiny-ploc'])
+@pytest.fixture(scope='module', params=['cube-collapse', 'cube-sah', 'cube-greedy', 'cube-ploc', 'cube-levels', 'tiny-collapse', 'tiny-sah', 'tiny-greedy', 'tiny-ploc', 'tiny-levels'])
 def built(request):
     want, topology = request.param.split('-')
     for name, g in _geometries():
@@ -135,7 +135,7 @@ def test_unlayered_and_overwide_trees():
     nodes.append(node(70, 72, tri, 0)); tri += 1
     nodes.append(node(75, 79, tri, 0)); tri += 1
     ref = np.array(nodes, dtype=np.uint32)
-    for topology in ('sah', 'greedy', 'collapse', 'ploc'):          # (ploc: not a tree that ends in its leaf layer -> the top-down builder)
+    for topology in ('sah', 'greedy', 'collapse', 'ploc', 'levels'):          # (ploc: not a tree that ends in its leaf layer -> the top-down builder)
         w = _wide(ref, tri, topology)
         ent = w['wnodes'].reshape(-1, 4)
         leaf = ent[(ent[:, 3] & LEAF != 0) & (ent[:, 3] != EMPTY)]
@@ -162,7 +162,7 @@ def test_build_is_repeatable():
         if name != 'tiny':
             continue
         nodes = np.ascontiguousarray(g.bvh.nodes)
-        for topology in ('sah', 'greedy', 'collapse', 'ploc'):
+        for topology in ('sah', 'greedy', 'collapse', 'ploc', 'levels'):
             a = _wide(nodes, len(g.mesh.triangles), topology)
             b = _wide(nodes, len(g.mesh.triangles), topology)
             for key in ('wnodes', 'tri_to_record', 'record_to_tri', 'rank'):
