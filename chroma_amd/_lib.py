@@ -154,6 +154,8 @@ SIGNATURES = {
     'chroma_bvh_free': (c_int32, [c_void_p]),
     'chroma_wide_build': (c_int32, [c_void_p, c_uint64, c_uint32, POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64),
                                     POINTER(c_uint32)]),
+    'chroma_wide_build_device': (c_int32, [c_void_p, c_void_p, c_uint64, c_uint32, POINTER(c_void_p), POINTER(c_uint64),
+                                           POINTER(c_uint64), POINTER(c_uint32)]),
     'chroma_wide_data': (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     'chroma_wide_free': (c_int32, [c_void_p]),
     'chroma_wide_validate': (c_int32, [c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_uint64]),
@@ -251,18 +253,23 @@ def bvh_build(vertices, triangles, world_origin, world_scale, target_degree=3, c
     return nodes, bounds.astype(np.int64)
 
 
-def wide_build(nodes, ntriangles):
-    """The derived 8-wide traversal tree of a reference-format BVH (host side; what
-    chroma_geometry_create uploads).  Returns a dict of copies: ``wnodes`` [nwide][8][4] uint32,
-    ``tri_to_record``, ``record_to_tri``, ``rank`` and ``depth``."""
-    lib = load()
+def wide_build(nodes, ntriangles, ctx=None):
+    """The derived 8-wide traversal tree of a reference-format BVH (what chroma_geometry_create uploads).
+    ``ctx`` None: built on the host cores (chroma_wide_build; topology by $CHROMA_TREE); a chroma_amd.gpu context:
+    built by HIP kernels on its device (chroma_wide_build_device: the "levels" topology).  Returns a dict of
+    copies: ``wnodes`` [nwide][8][4] uint32, ``tri_to_record``, ``record_to_tri``, ``rank`` and ``depth``."""
+    lib = load() if ctx is None else ctx._lib
     raw = np.ascontiguousarray(nodes).view(np.uint32).reshape(-1, 4)
     handle = c_void_p()
     nwide, nrec, depth = c_uint64(), c_uint64(), c_uint32()
-    rc = lib.chroma_wide_build(ptr(raw), len(raw), int(ntriangles), ctypes.byref(handle), ctypes.byref(nwide),
-                               ctypes.byref(nrec), ctypes.byref(depth))
-    if rc != 0:
-        raise ChromaError('chroma_wide_build failed (%d): malformed BVH' % rc)
+    if ctx is None:
+        rc = lib.chroma_wide_build(ptr(raw), len(raw), int(ntriangles), ctypes.byref(handle), ctypes.byref(nwide),
+                                   ctypes.byref(nrec), ctypes.byref(depth))
+        if rc != 0:
+            raise ChromaError('chroma_wide_build failed (%d): malformed BVH' % rc)
+    else:
+        check(lib.chroma_wide_build_device(ctx.handle, ptr(raw), len(raw), int(ntriangles), ctypes.byref(handle),
+                                           ctypes.byref(nwide), ctypes.byref(nrec), ctypes.byref(depth)))
     try:
         p = [c_void_p() for _ in range(4)]
         check(lib.chroma_wide_data(handle, *[ctypes.byref(x) for x in p]))

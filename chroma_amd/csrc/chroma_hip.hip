@@ -3888,8 +3888,17 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
             return set_error(CHROMA_ERR_INVALID, "geometry: a supplied wide tree needs its nodes, both record maps and the ranks");
         }
     } else {
+        // the default topology is built where the reference builds its tree: on the device (csrc/wide_device.hip);
+        // the others, and CHROMA_WIDE_BUILD=host, on the host cores (csrc/wide_build.cpp) -- "levels" gives the same tree either way
         std::string werr;
-        if (chroma_host::build_wide_tree(d->nodes, d->nnodes, d->ntriangles, wt, werr, chroma_host::wide_topology_from_env()) != 0) {
+        const int topology = chroma_host::wide_topology_from_env();
+        const char *where = getenv("CHROMA_WIDE_BUILD");
+        if (topology == chroma_host::WIDE_TOPOLOGY_LEVELS && !(where && !strcmp(where, "host"))) {
+            void *h = nullptr;
+            if ((rc = chroma_wide_build_device(ctx, d->nodes, d->nnodes, d->ntriangles, &h, nullptr, nullptr, nullptr)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; }
+            wt = std::move(*(chroma_host::WideTree *)h);
+            delete (chroma_host::WideTree *)h;
+        } else if (chroma_host::build_wide_tree(d->nodes, d->nnodes, d->ntriangles, wt, werr, topology) != 0) {
             chroma_geometry_destroy(g);
             return set_error(CHROMA_ERR_INVALID, "%s", werr.c_str());
         }

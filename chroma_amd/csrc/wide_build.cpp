@@ -844,17 +844,27 @@ static int levels_topology(const uint32_t *ref, uint32_t ntriangles, const std::
     return emit_breadth_first(d, 0, out, err);
 }
 
-int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, WideTree &out, std::string &err, int topology)
+// stack need and the record maps of a tree whose wnodes / dev_to_tri are made
+void finish_wide_tree(WideTree &out, uint32_t ntriangles)
 {
-    const bool timing = getenv("CHROMA_TIMING") != nullptr;
-    auto t_phase = std::chrono::steady_clock::now();
-    auto phase = [&](const char *what) {
-        if (!timing) return;
-        auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[build_wide_tree] %-28s %.2f s\n", what, std::chrono::duration<double>(now - t_phase).count());
-        t_phase = now;
-    };
-    out = WideTree();
+    out.tri_to_dev.assign(ntriangles, 0xFFFFFFFFu);
+    // worst case of the walk's stack: at a node, every inner child but the one walked next is
+    // pushed, then the same below -- whichever child is walked, so the maximum over children
+    out.stack_need = wide_stack_need(out.wnodes.data(), out.nwide);
+    // device index of every triangle (a triangle under several leaves keeps the first; triangles
+    // under no leaf go to the end so that every triangle has a record)
+    for (size_t d = 0; d < out.dev_to_tri.size(); d++) {
+        uint32_t t = out.dev_to_tri[d];
+        if (out.tri_to_dev[t] == 0xFFFFFFFFu) out.tri_to_dev[t] = (uint32_t)d;
+    }
+    for (uint32_t t = 0; t < ntriangles; t++)
+        if (out.tri_to_dev[t] == 0xFFFFFFFFu) { out.tri_to_dev[t] = (uint32_t)out.dev_to_tri.size(); out.dev_to_tri.push_back(t); }
+}
+
+// The reference's test order (see the header): `rank` of every triangle, and the reachable leaf that holds it.
+int reference_test_order(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, std::vector<uint32_t> &rank,
+                         std::vector<uint32_t> &leaf_node, std::string &err, size_t *nlayers_out, bool *layered_out)
+{
     if (!nodes || nnodes == 0) { err = "wide tree: no nodes"; return -1; }
 
     // ---- layers of the reference tree (root first, children behind their parents' layer); a tree
@@ -893,8 +903,8 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
     const uint32_t UNREACHED = 0xFFFFFFFFu;
     std::vector<uint32_t> leaves(nreach, 0), base(nreach, UNREACHED);
     base[0] = 0;
-    out.rank.assign(ntriangles, 0xFFFFFFFFu);
-    std::vector<uint32_t> leaf_node(ntriangles, 0xFFFFFFFFu);      // the reachable leaf that holds a triangle
+    rank.assign(ntriangles, 0xFFFFFFFFu);
+    leaf_node.assign(ntriangles, 0xFFFFFFFFu);      // the reachable leaf that holds a triangle
     std::atomic<int> bad(0);
     auto count_leaves = [&](size_t i) {
         uint32_t w = nodes[4 * i + 3], k = w >> NCHILD_SHIFT, c = w & CHILD_MASK;
@@ -912,7 +922,7 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
             if ((cw >> NCHILD_SHIFT) == 0) {
                 uint32_t t = cw & CHILD_MASK;
                 if (t >= ntriangles) { bad = 1; continue; }
-                if (out.rank[t] == 0xFFFFFFFFu) { out.rank[t] = run; leaf_node[t] = c + j; }   // (a duplicate leaf keeps one of its ranks)
+                if (rank[t] == 0xFFFFFFFFu) { rank[t] = run; leaf_node[t] = c + j; }   // (a duplicate leaf keeps one of its ranks)
                 run++;
             }
         }
@@ -935,10 +945,27 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
         for (size_t i = 0; i < nnodes; i++) assign_ranks(i);
     }
     if (bad) { err = "wide tree: leaf references a triangle outside the mesh"; return -1; }
-    { std::vector<uint32_t>().swap(base); std::vector<uint32_t>().swap(leaves); }
 
+    if (nlayers_out) *nlayers_out = nlayers;
+    if (layered_out) *layered_out = layered;
+    return 0;
+}
+
+int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, WideTree &out, std::string &err, int topology)
+{
+    const bool timing = getenv("CHROMA_TIMING") != nullptr;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char *what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[build_wide_tree] %-28s %.2f s\n", what, std::chrono::duration<double>(now - t_phase).count());
+        t_phase = now;
+    };
+    out = WideTree();
+    std::vector<uint32_t> leaf_node;
+    size_t nlayers = 0; bool layered = true;
+    if (reference_test_order(nodes, nnodes, ntriangles, out.rank, leaf_node, err, &nlayers, &layered) != 0) return -1;
     phase("reference test order");
-    out.tri_to_dev.assign(ntriangles, 0xFFFFFFFFu);
     out.dev_to_tri.clear();
     // (PLOC starts from the reference tree's leaf layer: its last ntriangles nodes, one leaf per triangle in Morton order --
     //  a tree that does not end that way keeps the top-down builder)
@@ -956,7 +983,7 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
         }
         if (!leaf_layer) topology = WIDE_TOPOLOGY_SAH;
     }
-    if (timing) fprintf(stderr, "[build_wide_tree] topology %d, layered %d, %zu layers, last layer [%zu, %zu)\n", topology, (int)layered, nlayers, layer_start[nlayers - 1], layer_start[nlayers]);
+    if (timing) fprintf(stderr, "[build_wide_tree] topology %d, layered %d, %zu layers\n", topology, (int)layered, nlayers);
     if (topology == WIDE_TOPOLOGY_PLOC) {
         if (ploc_topology(nodes, nnodes - ntriangles, nnodes, ntriangles, out, err) != 0) return -1;
     } else
@@ -1045,17 +1072,7 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
     }
 
     phase("topology");
-    // worst case of the walk's stack: at a node, every inner child but the one walked next is
-    // pushed, then the same below -- whichever child is walked, so the maximum over children
-    out.stack_need = wide_stack_need(out.wnodes.data(), out.nwide);
-    // device index of every triangle (a triangle under several leaves keeps the first; triangles
-    // under no leaf go to the end so that every triangle has a record)
-    for (size_t d = 0; d < out.dev_to_tri.size(); d++) {
-        uint32_t t = out.dev_to_tri[d];
-        if (out.tri_to_dev[t] == 0xFFFFFFFFu) out.tri_to_dev[t] = (uint32_t)d;
-    }
-    for (uint32_t t = 0; t < ntriangles; t++)
-        if (out.tri_to_dev[t] == 0xFFFFFFFFu) { out.tri_to_dev[t] = (uint32_t)out.dev_to_tri.size(); out.dev_to_tri.push_back(t); }
+    finish_wide_tree(out, ntriangles);
     phase("stack need + record map");
     return 0;
 }
@@ -1130,8 +1147,8 @@ int wide_topology_from_env()
     if (e && !strcmp(e, "collapse")) return WIDE_TOPOLOGY_COLLAPSE;
     if (e && !strcmp(e, "greedy")) return WIDE_TOPOLOGY_SAH_GREEDY;
     if (e && !strcmp(e, "ploc")) return WIDE_TOPOLOGY_PLOC;
-    if (e && !strcmp(e, "levels")) return WIDE_TOPOLOGY_LEVELS;
-    return WIDE_TOPOLOGY_SAH;
+    if (e && !strcmp(e, "sah")) return WIDE_TOPOLOGY_SAH;
+    return WIDE_TOPOLOGY_LEVELS;
 }
 
 }  // namespace chroma_host

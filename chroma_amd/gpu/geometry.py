@@ -43,12 +43,19 @@ class PackedGeometry(object):
         setattr(self.desc, name, a.ctypes.data if a.size else None)
         return a
 
-    def attach_wide_tree(self, wide=None):
+    def attach_wide_tree(self, wide=None, ctx='auto'):
         """Carry the derived 8-wide traversal tree along (``wide``: what chroma_amd._lib.wide_build returned
         for these nodes; None: build it now), so that chroma_geometry_create uploads it instead of deriving
-        it again -- once per cache file, or once per node when several processes drive one GPU each."""
+        it again -- once per cache file, or once per node when several processes drive one GPU each.
+        Built on the device of ``ctx`` ('auto': the current chroma_amd.gpu context if there is one and the
+        topology is the default; None: on the host cores) -- the same tree either way."""
         if wide is None:
-            wide = _lib.wide_build(self.arrays['nodes'], self.desc.ntriangles)
+            if ctx == 'auto':
+                import os
+                from chroma_amd.gpu import tools as gtools
+                default = os.environ.get('CHROMA_TREE', 'levels') == 'levels' and os.environ.get('CHROMA_WIDE_BUILD') != 'host'
+                ctx = gtools._current if default else None
+            wide = _lib.wide_build(self.arrays['nodes'], self.desc.ntriangles, ctx=ctx)
         self.put('wide_nodes', wide['wnodes'], np.uint32)
         self.put('wide_tri_to_record', wide['tri_to_record'], np.uint32)
         self.put('wide_record_to_tri', wide['record_to_tri'], np.uint32)

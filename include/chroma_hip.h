@@ -410,6 +410,11 @@ int chroma_bvh_free(void *handle);
  *   record_to_tri [nrecords] uint32       rank [ntriangles] uint32 (0xFFFFFFFF: under no leaf) */
 int chroma_wide_build(const uint32_t *nodes, uint64_t nnodes, uint32_t ntriangles, void **handle,
                       uint64_t *nwide, uint64_t *nrecords, uint32_t *depth);
+/* The same step ON THE DEVICE of `ctx` (csrc/wide_device.hip): HIP kernels over one level of the tree at a time -- the
+ * place where the reference builds its own tree (chroma/gpu/bvh.py, chroma/cuda/bvh.cu run on the GPU).  The result is the
+ * tree CHROMA_TREE=levels makes on the host, bit for bit (tests/test_gpu_wide.py); same handle, same accessors. */
+int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nnodes, uint32_t ntriangles, void **handle,
+                             uint64_t *nwide, uint64_t *nrecords, uint32_t *depth);
 int chroma_wide_data(void *handle, const uint32_t **wnodes, const uint32_t **tri_to_record,
                      const uint32_t **record_to_tri, const uint32_t **rank);
 int chroma_wide_free(void *handle);

@@ -13,7 +13,7 @@ def main():
     from chroma_amd import demo, gpu, _lib
     from chroma_amd.loader import create_geometry_from_obj
     from chroma_amd.gpu.geometry import pack_geometry
-    config = sys.argv[1] if len(sys.argv) > 1 else 'c3'
+    config = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith('-') else 'c3'
     builder = bench.CONFIGS[config][0]
     ctx = gpu.create_cuda_context(0)
     t = [time.time()]
@@ -31,8 +31,14 @@ def main():
     t.append(time.time())
     gg = gpu.GPUDetector.from_packed(packed)
     t.append(time.time())
+    if '--check' in sys.argv:          # the device tree against its host twin (CHROMA_TREE=levels on the host cores)
+        t0 = time.time()
+        host = _lib.wide_build(packed.arrays['nodes'], packed.desc.ntriangles)
+        same = all(np.array_equal(np.asarray(host[k]).reshape(-1), np.asarray(packed.arrays[a]).reshape(-1)) for k, a in (
+            ('wnodes', 'wide_nodes'), ('tri_to_record', 'wide_tri_to_record'), ('record_to_tri', 'wide_record_to_tri'), ('rank', 'wide_rank')))
+        print('device tree == host twin: %s (host build %.1f s)' % (same, time.time() - t0))
     names = ['demo.%s() (solids placed)' % builder, 'create_geometry_from_obj (flatten + a-20 BVH)', 'pack_geometry (tables, arrays)',
-             'attach_wide_tree (binary SAH tree + collapse, host)', 'GPUDetector.from_packed (validation + upload)']
+             'attach_wide_tree (SAH tree + collapse; device when a context is current)', 'GPUDetector.from_packed (validation + upload)']
     d = packed.desc
     print('%s: %d triangles, %d nodes, %d wide nodes' % (config, d.ntriangles, d.nnodes, d.nwide))
     for n, a, b in zip(names, t[:-1], t[1:]):
