@@ -257,7 +257,7 @@ def wide_build(nodes, ntriangles, ctx=None):
     """The derived 8-wide traversal tree of a reference-format BVH (what chroma_geometry_create uploads).
     ``ctx`` None: built on the host cores (chroma_wide_build; topology by $CHROMA_TREE); a chroma_amd.gpu context:
     built by HIP kernels on its device (chroma_wide_build_device: the "levels" topology).  Returns a dict of
-    copies: ``wnodes`` [nwide][8][4] uint32, ``tri_to_record``, ``record_to_tri``, ``rank`` and ``depth``."""
+    arrays (views of the builder's buffers): ``wnodes`` [nwide][8][4] uint32, ``tri_to_record``, ``record_to_tri``, ``rank`` and ``depth``."""
     lib = load() if ctx is None else ctx._lib
     raw = np.ascontiguousarray(nodes).view(np.uint32).reshape(-1, 4)
     handle = c_void_p()
@@ -270,19 +270,27 @@ def wide_build(nodes, ntriangles, ctx=None):
     else:
         check(lib.chroma_wide_build_device(ctx.handle, ptr(raw), len(raw), int(ntriangles), ctypes.byref(handle),
                                            ctypes.byref(nwide), ctypes.byref(nrec), ctypes.byref(depth)))
-    try:
-        p = [c_void_p() for _ in range(4)]
-        check(lib.chroma_wide_data(handle, *[ctypes.byref(x) for x in p]))
+    # views of the builder's own buffers (no copies: 4 GB of wide nodes at 170 M triangles); the handle is released when
+    # the last of them is garbage-collected
+    class _Owner(object):
+        def __init__(self, free, h):
+            self.free, self.h = free, h
 
-        def copy(pp, n):
-            if n == 0:
-                return np.zeros(0, dtype=np.uint32)
-            return np.array((ctypes.c_uint32 * n).from_address(pp.value), dtype=np.uint32)
-        return {'wnodes': copy(p[0], 32 * nwide.value).reshape(-1, 8, 4),
-                'tri_to_record': copy(p[1], int(ntriangles)), 'record_to_tri': copy(p[2], nrec.value),
-                'rank': copy(p[3], int(ntriangles)), 'depth': depth.value}
-    finally:
-        lib.chroma_wide_free(handle)
+        def __del__(self):
+            self.free(self.h)
+    owner = _Owner(lib.chroma_wide_free, handle)
+    p = [c_void_p() for _ in range(4)]
+    check(lib.chroma_wide_data(handle, *[ctypes.byref(x) for x in p]))
+
+    def view(pp, n):
+        if n == 0:
+            return np.zeros(0, dtype=np.uint32)
+        raw = (ctypes.c_uint32 * n).from_address(pp.value)
+        raw._owner = owner
+        return np.frombuffer(raw, dtype=np.uint32)
+    return {'wnodes': view(p[0], 32 * nwide.value).reshape(-1, 8, 4),
+            'tri_to_record': view(p[1], int(ntriangles)), 'record_to_tri': view(p[2], nrec.value),
+            'rank': view(p[3], int(ntriangles)), 'depth': depth.value}
 
 
 def wide_validate(wide, ntriangles):

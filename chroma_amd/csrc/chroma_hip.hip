@@ -3360,27 +3360,62 @@ static int upload(chroma_geometry *g, const T *host, size_t count, const T **dev
 // Worst-case number of simultaneously live stack entries of the depth-first walk in
 // intersect_mesh for this tree (every box test succeeding).  Children always have larger
 // indices than their parent (layers are stored root first), so one backward sweep suffices.
-static uint32_t compute_stack_need(const uint32_t *nodes, size_t nnodes)
+// Most entries a walk's stack can hold at once, for the two trees of a geometry, from the arrays AS UPLOADED.
+// need(node) = max over its inner children c, in push order, of (inner children before c) + need(c) [reference walk, mesh.h:68-110],
+// need(node) = inner children - 1 + max need(child) [nearest-first wide walk].  Children follow their parents in both arrays, so
+// the values are the least fixed point of these rules: every pass over the array only raises entries, and after (depth of the
+// tree) passes nothing changes -- ~30 passes of a few milliseconds instead of a second-long backward sweep on one host core.
+__global__ void k_stack_need_ref(const uint4 *nodes, uint32_t nnodes, uint32_t *need, uint32_t *changed)
 {
-    std::vector<uint16_t> need(nnodes, 0);
-    for (size_t i = nnodes; i-- > 0;) {
-        uint32_t w = nodes[4 * i + 3];
-        uint32_t nchild = w >> CHROMA_CHILD_BITS, first = w & ~CHROMA_NCHILD_MASK;
-        if (nchild == 0) continue;
-        if ((size_t)first + nchild > nnodes || first <= i) { need[i] = 0xFFFF; continue; }
-        uint32_t rank = 0, best = 0;
-        for (uint32_t j = 0; j < nchild; j++) {
-            size_t c = (size_t)first + j;
-            bool internal = (nodes[4 * c + 3] >> CHROMA_CHILD_BITS) != 0;
-            if (internal) {
-                best = std::max(best, rank + (uint32_t)need[c]);
-                rank++;
-            }
-        }
-        best = std::max(best, rank);
-        need[i] = (uint16_t)std::min(best, 0xFFFFu);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnodes) return;
+    const uint32_t w = nodes[i].w, nchild = w >> CHROMA_CHILD_BITS, first = w & ~CHROMA_NCHILD_MASK;
+    if (nchild == 0) return;
+    uint32_t best = 0;
+    if ((uint64_t)first + nchild > nnodes || first <= i) best = 0xFFFFu;
+    else {
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nchild; j++)
+            if ((nodes[first + j].w >> CHROMA_CHILD_BITS) != 0) { best = max(best, rank + need[first + j]); rank++; }
+        best = min(max(best, rank), 0xFFFFu);
     }
-    return std::max<uint32_t>(1, need[0]);
+    if (best != need[i]) { need[i] = best; *changed = 1u; }
+}
+__global__ void k_stack_need_wide(const uint4 *wnodes, uint32_t nwide, uint32_t *need, uint32_t *changed)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwide) return;
+    uint32_t inner = 0, below = 0;
+    for (int j = 0; j < 8; j++) {
+        const uint32_t w = wnodes[8 * (size_t)i + j].w;
+        if (w == 0xFFFFFFFFu || (w & 0x80000000u)) continue;
+        inner++;
+        if (w < nwide && w > i) below = max(below, need[w]);
+    }
+    const uint32_t v = min(0xFFFFu, inner ? inner - 1u + below : 0u);
+    if (v != need[i]) { need[i] = v; *changed = 1u; }
+}
+// runs `pass` until an entry no longer changes; returns need[0]
+template <class Pass>
+static int stack_need_fixed_point(chroma_ctx *ctx, size_t n, Pass pass, uint32_t *result)
+{
+    uint32_t *d_need = nullptr, *d_changed = nullptr;
+    HIP_TRY(hipMalloc(&d_need, std::max<size_t>(n, 1) * 4));
+    if (hipMalloc(&d_changed, 4) != hipSuccess) { hipFree(d_need); return set_error(CHROMA_ERR_INTERNAL, "out of device memory"); }
+    hipError_t e = hipMemsetAsync(d_need, 0, std::max<size_t>(n, 1) * 4, ctx->stream);
+    uint32_t changed = 1, h_need = 0;
+    for (int it = 0; e == hipSuccess && changed && it < 8192; it++) {
+        e = hipMemsetAsync(d_changed, 0, 4, ctx->stream);
+        for (int k = 0; k < 4; k++) pass(d_need, d_changed);                    // (four passes per question)
+        if (e == hipSuccess) e = hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(&h_need, d_need, 4, hipMemcpyDeviceToHost);
+    hipFree(d_need); hipFree(d_changed);
+    if (e != hipSuccess) return set_error((int)e, "stack need: %s", hipGetErrorString(e));
+    if (changed) return set_error(CHROMA_ERR_INVALID, "stack need: the tree does not settle (a child range that points back?)");
+    *result = h_need;
+    return CHROMA_OK;
 }
 
 // ---- distance_to_mesh through the fast ray cast --------------------------------------------------------
@@ -3772,13 +3807,57 @@ int chroma_upload(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes
     return CHROMA_OK;
 }
 
-int chroma_memcpy_dtoh(chroma_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes)
+// ---- device -> host: the same ring the other way round -- a piece comes down by DMA into a pinned buffer while the host
+// threads copy the previous one out to (pageable, possibly never touched) destination memory in parallel
+static int staged_dtoh(chroma_ctx *ctx, hipStream_t stream, void *h_dst, const void *d_src, size_t nbytes)
 {
-    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    std::lock_guard<std::mutex> lock(ctx->stage_mu);
+    for (int i = 0; i < chroma_ctx::STAGE_N; i++)
+        if (!ctx->stage[i]) {
+            HIP_TRY(hipHostMalloc(&ctx->stage[i], chroma_ctx::STAGE_BYTES, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+        }
+    const size_t npieces = (nbytes + chroma_ctx::STAGE_BYTES - 1) / chroma_ctx::STAGE_BYTES;
+    auto issue = [&](size_t i) -> hipError_t {
+        const size_t off = i * chroma_ctx::STAGE_BYTES, len = std::min(chroma_ctx::STAGE_BYTES, nbytes - off);
+        const int k = (int)(i % chroma_ctx::STAGE_N);
+        hipError_t e = hipMemcpyAsync(ctx->stage[k], (const char *)d_src + off, len, hipMemcpyDeviceToHost, stream);
+        return e != hipSuccess ? e : hipEventRecord(ctx->stage_ev[k], stream);
+    };
+    HIP_TRY(issue(0));
+    for (size_t i = 0; i < npieces; i++) {
+        if (i + 1 < npieces) HIP_TRY(issue(i + 1));               // (its buffer was copied out two pieces ago)
+        const size_t off = i * chroma_ctx::STAGE_BYTES, len = std::min(chroma_ctx::STAGE_BYTES, nbytes - off);
+        const int k = (int)(i % chroma_ctx::STAGE_N);
+        HIP_TRY(hipEventSynchronize(ctx->stage_ev[k]));
+        const char *src = (const char *)ctx->stage[k];
+        char *dst = (char *)h_dst + off;
+        chroma_host::parallel_for(len, [&](size_t a, size_t b) { memcpy(dst + a, src + a, b - a); }, 1u << 20);
+    }
+    return CHROMA_OK;
+}
+// for the other translation units of the library (ctx_access.h): a large download on the context's stream
+extern "C" int chroma_internal_dtoh(chroma_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes)
+{
     if (nbytes == 0) return CHROMA_OK;
+    if (nbytes >= (8u << 20)) return staged_dtoh(ctx, ctx->stream, h_dst, d_src, nbytes);
     HIP_TRY(hipMemcpyAsync(h_dst, d_src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return CHROMA_OK;
+}
+extern "C" int chroma_internal_htod(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes)
+{
+    if (nbytes == 0) return CHROMA_OK;
+    if (nbytes >= (8u << 20)) return staged_htod(ctx, ctx->stream, d_dst, h_src, nbytes);
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CHROMA_OK;
+}
+
+int chroma_memcpy_dtoh(chroma_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    return chroma_internal_dtoh(ctx, h_dst, d_src, nbytes);
 }
 
 int chroma_memcpy_dtod(chroma_ctx *ctx, void *d_dst, const void *d_src, size_t nbytes)
@@ -3921,8 +4000,17 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     { const uint4 *p; if ((rc = upload(g, (const uint4 *)wide_nodes, nwide * 8, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } v.wnodes = p; }
     v.nwide = (uint32_t)nwide;
     g->nwide = nwide; g->wide_depth = wt.depth; g->nrecords = nrecords;
-    g->wide_stack_need = wide_given ? chroma_host::wide_stack_need(wide_nodes, nwide) : wt.stack_need;
-    { std::vector<uint32_t>().swap(wt.wnodes); }
+    {
+        const uint4 *dw = v.wnodes;
+        const uint32_t nw = (uint32_t)nwide;
+        hipStream_t st = ctx->stream;
+        if ((rc = stack_need_fixed_point(ctx, nwide, [&](uint32_t *need, uint32_t *changed) {
+                 hipLaunchKernelGGL(k_stack_need_wide, dim3((nw + 255) / 256), dim3(256), 0, st, dw, nw, need, changed); }, &g->wide_stack_need)) != CHROMA_OK) {
+            chroma_geometry_destroy(g);
+            return rc;
+        }
+    }
+    { chroma_host::WordBuffer().swap(wt.wnodes); }
     UP(tri_to_dev, tri_to_dev, d->ntriangles);
     UP(dev_to_tri, dev_to_tri, nrecords);
     // traversal copy of the nodes: leaf child -> device triangle index
@@ -4041,7 +4129,18 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     if (getenv("CHROMA_FULL_PHYSICS")) v.plain_optics = 0u;          // (A/B: the all-models kernel on a plain geometry)
 
     phase("mesh arrays + tables");
-    g->stack_need = compute_stack_need(d->nodes, d->nnodes);
+    {
+        const uint4 *dn = (const uint4 *)g->d_nodes_api;
+        const uint32_t nn = (uint32_t)d->nnodes;
+        hipStream_t st = ctx->stream;
+        uint32_t need = 0;
+        if ((rc = stack_need_fixed_point(ctx, d->nnodes, [&](uint32_t *nd, uint32_t *changed) {
+                 hipLaunchKernelGGL(k_stack_need_ref, dim3((nn + 255) / 256), dim3(256), 0, st, dn, nn, nd, changed); }, &need)) != CHROMA_OK) {
+            chroma_geometry_destroy(g);
+            return rc;
+        }
+        g->stack_need = std::max<uint32_t>(1, need);
+    }
     phase("stack need");
     if (g->stack_need > STACK_LDS + STACK_SCRATCH) {
         uint32_t need = g->stack_need;

@@ -8,4 +8,8 @@ extern "C" {
 hipStream_t chroma_internal_stream(chroma_ctx *ctx);
 int chroma_internal_device(chroma_ctx *ctx);
 int chroma_internal_set_error(int code, const char *fmt, ...);      // returns `code`
+// copies of any size between host memory (pageable is fine) and the device, through the context's pinned staging ring;
+// both return when the data has arrived
+int chroma_internal_dtoh(chroma_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes);
+int chroma_internal_htod(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes);
 }

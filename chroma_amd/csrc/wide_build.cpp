@@ -845,20 +845,29 @@ static int levels_topology(const uint32_t *ref, uint32_t ntriangles, const std::
 }
 
 // stack need and the record maps of a tree whose wnodes / dev_to_tri are made
-void finish_wide_tree(WideTree &out, uint32_t ntriangles)
+void finish_wide_tree(WideTree &out, uint32_t ntriangles, bool with_stack_need)
 {
     out.tri_to_dev.assign(ntriangles, 0xFFFFFFFFu);
     // worst case of the walk's stack: at a node, every inner child but the one walked next is
     // pushed, then the same below -- whichever child is walked, so the maximum over children
-    out.stack_need = wide_stack_need(out.wnodes.data(), out.nwide);
+    // (chroma_geometry_create works it out on the device for the tree it uploads: the device builder skips it here)
+    out.stack_need = with_stack_need ? wide_stack_need(out.wnodes.data(), out.nwide) : 0u;
     // device index of every triangle (a triangle under several leaves keeps the first; triangles
     // under no leaf go to the end so that every triangle has a record)
-    for (size_t d = 0; d < out.dev_to_tri.size(); d++) {
-        uint32_t t = out.dev_to_tri[d];
-        if (out.tri_to_dev[t] == 0xFFFFFFFFu) out.tri_to_dev[t] = (uint32_t)d;
-    }
-    for (uint32_t t = 0; t < ntriangles; t++)
-        if (out.tri_to_dev[t] == 0xFFFFFFFFu) { out.tri_to_dev[t] = (uint32_t)out.dev_to_tri.size(); out.dev_to_tri.push_back(t); }
+    uint32_t *t2d = out.tri_to_dev.data();
+    const uint32_t *d2t = out.dev_to_tri.data();
+    parallel_for(out.dev_to_tri.size(), [&](size_t a, size_t b) {
+        for (size_t d = a; d < b; d++) {
+            uint32_t *slot = t2d + d2t[d];
+            uint32_t cur = __atomic_load_n(slot, __ATOMIC_RELAXED);
+            while ((uint32_t)d < cur && !__atomic_compare_exchange_n(slot, &cur, (uint32_t)d, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        }
+    });
+    std::atomic<int> unmapped(0);
+    parallel_for(ntriangles, [&](size_t a, size_t b) { for (size_t t = a; t < b; t++) if (t2d[t] == 0xFFFFFFFFu) { unmapped = 1; break; } });
+    if (unmapped)
+        for (uint32_t t = 0; t < ntriangles; t++)
+            if (out.tri_to_dev[t] == 0xFFFFFFFFu) { out.tri_to_dev[t] = (uint32_t)out.dev_to_tri.size(); out.dev_to_tri.push_back(t); }
 }
 
 // The reference's test order (see the header): `rank` of every triangle, and the reachable leaf that holds it.

@@ -2,7 +2,10 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <memory>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace chroma_host {
@@ -19,8 +22,18 @@ enum { WIDE_TOPOLOGY_COLLAPSE = 0,     // the reference tree with children pulle
                                        // partitions, the least-area collapse over the whole tree, breadth-first node order -- what the device
                                        // builder (csrc/wide_device.hip) makes, bit for bit.  THE DEFAULT.
 
+// a vector whose resize() leaves new elements uninitialised: 4 GB of wide nodes are written once, by the builder, not
+// zeroed first by one thread (assign / resize(n, value) still fill)
+template <class T> struct default_init_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_allocator<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<uint32_t, default_init_allocator<uint32_t>> WordBuffer;
+
 struct WideTree {
-    std::vector<uint32_t> wnodes;       // nwide * 8 entries of 4 words: x, y, z boxes, w = child (see above)
+    WordBuffer wnodes;       // nwide * 8 entries of 4 words: x, y, z boxes, w = child (see above)
     std::vector<uint32_t> tri_to_dev;   // [ntriangles] device record index of a triangle
     std::vector<uint32_t> dev_to_tri;   // [nrecords >= ntriangles] triangle of a device record
     std::vector<uint32_t> rank;         // [ntriangles] position in the reference's test order (0xFFFFFFFF: under no leaf)
@@ -38,7 +51,7 @@ int build_wide_tree(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, W
 int reference_test_order(const uint32_t *nodes, size_t nnodes, uint32_t ntriangles, std::vector<uint32_t> &rank,
                          std::vector<uint32_t> &leaf_node, std::string &err, size_t *nlayers = nullptr, bool *layered = nullptr);
 // and, once wnodes / nwide / depth / dev_to_tri are made, the stack need and the record maps.
-void finish_wide_tree(WideTree &out, uint32_t ntriangles);
+void finish_wide_tree(WideTree &out, uint32_t ntriangles, bool with_stack_need = true);
 // most entries the nearest-first walk over this tree can hold at once (children follow their parents)
 uint32_t wide_stack_need(const uint32_t *wnodes, size_t nwide);
 // Index checks of a wide tree and its record maps (see wide_build.cpp).  Returns 0, or -1 with `err` set.

@@ -175,6 +175,63 @@ __global__ void k_make_prims(const uint4 *nodes, const uint32_t *leaf_node, cons
 }
 __global__ void k_last_sum(const uint32_t *a, const uint32_t *b, uint32_t n, uint32_t *out) { if (threadIdx.x == 0 && blockIdx.x == 0) *out = n ? a[n - 1] + b[n - 1] : 0u; }
 
+// ---- the reference's test order (reference_test_order of wide_build.cpp) ---------------------------------------------------
+// The host code sweeps the node array layer by layer -- or, when the array is not stored that way (a chroma tree with collapsed
+// single-child chains is not: a collapsed node's children sit two layers down), sequentially.  Here the two recurrences are
+// solved by PASSES over the whole array until nothing changes (children follow their parents, so the depth of the tree bounds
+// the number of passes): leaves(node) = sum of leaves(children) rises to its value from below; base(child) -- the rank of the
+// first leaf tested under it -- is written once its parent's is known, with its final value.
+constexpr uint32_t NCHILD_SHIFT = 28, CHILD_MASK = 0x0FFFFFFFu, UNREACHED = 0xFFFFFFFFu;
+__global__ void k_ref_count_leaves(const uint4 *nodes, uint32_t nnodes, uint32_t *leaves, uint32_t *flags /* [0] changed, [1] bad */)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnodes) return;
+    const uint32_t w = nodes[i].w, k = w >> NCHILD_SHIFT, c = w & CHILD_MASK;
+    uint32_t s = 1u;
+    if (k) {
+        if ((uint64_t)c + k > nnodes || c <= i) { flags[1] = 1u; return; }
+        s = 0u;
+        for (uint32_t j = 0; j < k; j++) s += leaves[c + j];
+    }
+    if (leaves[i] != s) { leaves[i] = s; flags[0] = 1u; }
+}
+// leaves of a range take their ranks in order, then the inner children -- last first -- take the ranks of their subtrees
+// (a triangle under several leaves keeps its least rank: one 64-bit minimum of rank << 32 | leaf node)
+__global__ void k_ref_assign(const uint4 *nodes, uint32_t nnodes, const uint32_t *leaves, uint32_t *base, uint32_t ntriangles,
+                             unsigned long long *rank_leaf, uint32_t *flags /* [0] changed, [1] bad */)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnodes) return;
+    const uint32_t w = nodes[i].w, k = w >> NCHILD_SHIFT, c = w & CHILD_MASK;
+    if (k == 0u) return;
+    uint32_t run = base[i];
+    if (run == UNREACHED) return;
+    for (uint32_t j = 0; j < k; j++) {
+        const uint32_t cw = nodes[c + j].w;
+        if ((cw >> NCHILD_SHIFT) == 0u) {
+            const uint32_t t = cw & CHILD_MASK;
+            if (t >= ntriangles) { flags[1] = 1u; continue; }
+            atomicMin(rank_leaf + t, (unsigned long long)run << 32 | (unsigned long long)(c + j));
+            run++;
+        }
+    }
+    for (uint32_t j = k; j-- > 0u;) {
+        const uint32_t cw = nodes[c + j].w;
+        if ((cw >> NCHILD_SHIFT) != 0u) {
+            if (base[c + j] != run) { base[c + j] = run; flags[0] = 1u; }
+            run += leaves[c + j];
+        }
+    }
+}
+__global__ void k_ref_unpack(const unsigned long long *rank_leaf, uint32_t ntriangles, uint32_t *rank, uint32_t *leaf_node)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntriangles) return;
+    const unsigned long long v = rank_leaf[t];
+    rank[t] = v == ~0ull ? 0xFFFFFFFFu : (uint32_t)(v >> 32);
+    leaf_node[t] = v == ~0ull ? 0xFFFFFFFFu : (uint32_t)v;
+}
+
 // ---- a level, top-down ---------------------------------------------------------------------------------------------------
 __global__ void k_classify(const uint4 *segs, uint32_t nseg, const uint4 *in, uint4 *bin, uint32_t *dev_to_tri, uint32_t *flag,
                            uint32_t *list_small, uint32_t *list_wave, uint32_t *list_large, uint32_t *counters)
@@ -604,21 +661,49 @@ int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nn
     Lap lap(stream);
     WideTree *t = new WideTree;
     struct Guard { WideTree *t; ~Guard() { delete t; } } guard{t};
-    std::string err;
-    std::vector<uint32_t> leaf_node;
-    if (chroma_host::reference_test_order(nodes, (size_t)nnodes, ntriangles, t->rank, leaf_node, err) != 0)
-        return chroma_internal_set_error(CHROMA_ERR_INVALID, "chroma_wide_build_device: %s", err.c_str());
-    lap.lap("reference test order (host)");
-
+    if (nnodes >= 0xFFFFFFFFull) return chroma_internal_set_error(CHROMA_ERR_INVALID, "chroma_wide_build_device: too many nodes");
     Arena arena;
-    // ---- triangles of the builder
     uint4 *d_nodes; uint32_t *d_leaf_node, *d_flag, *d_rank, *d_counters;
     DEV_TRY(arena.get(&d_nodes, (size_t)nnodes));
     DEV_TRY(arena.get(&d_leaf_node, ntriangles));
     DEV_TRY(arena.get(&d_flag, ntriangles)); DEV_TRY(arena.get(&d_rank, ntriangles));
     DEV_TRY(arena.get(&d_counters, 8));
-    DEV_TRY(hipMemcpyAsync(d_nodes, nodes, (size_t)nnodes * 16u, hipMemcpyHostToDevice, stream));
-    DEV_TRY(hipMemcpyAsync(d_leaf_node, leaf_node.data(), (size_t)ntriangles * 4u, hipMemcpyHostToDevice, stream));
+    { const int rc_ = chroma_internal_htod(ctx, d_nodes, nodes, (size_t)nnodes * 16u); if (rc_ != CHROMA_OK) return rc_; }
+    lap.lap("nodes upload");
+
+    // ---- the reference's test order: leaves under every node, then ranks (passes until nothing changes)
+    std::vector<uint32_t> leaf_node;              // (host copy: only for a tree of one triangle)
+    {
+        const uint32_t nn = (uint32_t)nnodes;
+        uint32_t *d_leaves, *d_base; unsigned long long *d_rank_leaf;
+        DEV_TRY(arena.get(&d_leaves, nn)); DEV_TRY(arena.get(&d_base, nn)); DEV_TRY(arena.get(&d_rank_leaf, ntriangles));
+        DEV_TRY(hipMemsetAsync(d_leaves, 0, (size_t)nn * 4u, stream));
+        DEV_TRY(hipMemsetAsync(d_base, 0xFF, (size_t)nn * 4u, stream));
+        DEV_TRY(hipMemsetAsync(d_base, 0, 4, stream));
+        DEV_TRY(hipMemsetAsync(d_rank_leaf, 0xFF, (size_t)ntriangles * 8u, stream));
+        for (int phase = 0; phase < 2; phase++) {
+            uint32_t h[2] = {1u, 0u};
+            for (int it = 0; h[0] && !h[1]; it++) {
+                if (it > 4096) return chroma_internal_set_error(CHROMA_ERR_INVALID, "chroma_wide_build_device: the reference tree does not settle");
+                DEV_TRY(hipMemsetAsync(d_counters, 0, 2 * sizeof(uint32_t), stream));
+                for (int k = 0; k < 4; k++) {                    // (four passes per question)
+                    if (phase == 0) hipLaunchKernelGGL(k_ref_count_leaves, dim3(blocks_for(nn)), dim3(256), 0, stream, d_nodes, nn, d_leaves, d_counters);
+                    else hipLaunchKernelGGL(k_ref_assign, dim3(blocks_for(nn)), dim3(256), 0, stream, d_nodes, nn, d_leaves, d_base, ntriangles, d_rank_leaf, d_counters);
+                }
+                DEV_TRY(hipMemcpyAsync(h, d_counters, sizeof h, hipMemcpyDeviceToHost, stream));
+                DEV_TRY(hipStreamSynchronize(stream));
+            }
+            if (h[1]) return chroma_internal_set_error(CHROMA_ERR_INVALID, phase == 0 ? "chroma_wide_build_device: wide tree: bad child range"
+                                                                                        : "chroma_wide_build_device: wide tree: leaf references a triangle outside the mesh");
+        }
+        if (ntriangles) hipLaunchKernelGGL(k_ref_unpack, dim3(blocks_for(ntriangles)), dim3(256), 0, stream, d_rank_leaf, ntriangles, d_rank, d_leaf_node);
+        DEV_TRY(hipGetLastError());
+        DEV_TRY(hipStreamSynchronize(stream));
+        t->rank.resize(ntriangles);
+        { const int rc_ = chroma_internal_dtoh(ctx, t->rank.data(), d_rank, (size_t)ntriangles * 4u); if (rc_ != CHROMA_OK) return rc_; }
+        arena.release(d_leaves); arena.release(d_base); arena.release(d_rank_leaf);
+        lap.lap("reference test order");
+    }
     size_t tmp_bytes = 0;
     { uint32_t *nul = nullptr; DEV_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, nul, nul, (int)std::max<uint32_t>(ntriangles, 1u), stream)); }
     uint8_t *d_tmp;
@@ -637,6 +722,10 @@ int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nn
         t->wnodes.assign(32, 0);
         for (int i = 0; i < 8; i++) { uint32_t *o = t->wnodes.data() + 4 * i; o[0] = o[1] = o[2] = 0x0000FFFFu; o[3] = WIDE_EMPTY; }
         if (np == 1) {
+            if (leaf_node.empty()) {
+                leaf_node.resize(ntriangles);
+                DEV_TRY(hipMemcpy(leaf_node.data(), d_leaf_node, (size_t)ntriangles * 4u, hipMemcpyDeviceToHost));
+            }
             uint32_t tri = 0;
             while (leaf_node[tri] == 0xFFFFFFFFu) tri++;          // the one triangle under a reachable leaf
             memcpy(t->wnodes.data(), nodes + 4 * (size_t)leaf_node[tri], 12);
@@ -724,8 +813,7 @@ int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nn
     }
     if ((size_t)base + nseg != nb) return chroma_internal_set_error(CHROMA_ERR_INTERNAL, "chroma_wide_build_device: %zu binary nodes made, %zu expected", (size_t)base + nseg, nb);
     t->dev_to_tri.resize(np);
-    DEV_TRY(hipMemcpyAsync(t->dev_to_tri.data(), d_dev_to_tri, (size_t)np * 4u, hipMemcpyDeviceToHost, stream));
-    DEV_TRY(hipStreamSynchronize(stream));
+    { const int rc_ = chroma_internal_dtoh(ctx, t->dev_to_tri.data(), d_dev_to_tri, (size_t)np * 4u); if (rc_ != CHROMA_OK) return rc_; }
     arena.release(d_prims_a); arena.release(d_prims_b); arena.release(d_segs_a); arena.release(d_segs_b); arena.release(d_flag); arena.release(d_rank);
     arena.release(d_dev_to_tri);
     for (int c = 0; c < 3; c++) arena.release(d_list[c]);
@@ -753,6 +841,7 @@ int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nn
     { const uint32_t root = 0; DEV_TRY(hipMemcpyAsync(d_level, &root, 4, hipMemcpyHostToDevice, stream)); }
     size_t wbase = 0;
     uint32_t wdepth = 0;
+    t->wnodes.reserve(((size_t)np / 3 + 1024) * 32);          // (address space only: a node per ~5.6 triangles at C3)
     d_items = d_info = d_ninner = d_first = nullptr;
     while (cnt) {
         if (wbase + cnt > 0x7FFFFFFFull) return chroma_internal_set_error(CHROMA_ERR_INVALID, "chroma_wide_build_device: more than 2^31 wide nodes");
@@ -774,8 +863,7 @@ int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nn
                            (uint32_t)(wbase + cnt), d_w, d_next);
         DEV_TRY(hipGetLastError());
         t->wnodes.resize((wbase + cnt) * 32);
-        DEV_TRY(hipMemcpyAsync(t->wnodes.data() + wbase * 32, d_w, (size_t)cnt * 128u, hipMemcpyDeviceToHost, stream));
-        DEV_TRY(hipStreamSynchronize(stream));
+        { const int rc_ = chroma_internal_dtoh(ctx, t->wnodes.data() + wbase * 32, d_w, (size_t)cnt * 128u); if (rc_ != CHROMA_OK) return rc_; }
         arena.release(d_w); arena.release(d_level);
         d_level = d_next;
         wbase += cnt;
@@ -785,8 +873,8 @@ int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nn
     t->nwide = wbase;
     t->depth = wdepth;
     lap.lap("wide nodes + download");
-    chroma_host::finish_wide_tree(*t, ntriangles);
-    lap.lap("stack need + record map (host)");
+    chroma_host::finish_wide_tree(*t, ntriangles, false);
+    lap.lap("record map (host)");
     guard.t = nullptr;
     *handle = t;
     if (nwide) *nwide = t->nwide;
