@@ -20,10 +20,31 @@ import numpy as np
 from chroma_amd.bvh.bvh import BVH, WorldCoords, uint4, CHILD_BITS, MAX_CHILD
 
 
+def _bounds(vertices):
+    """(min, max) over the rows of an (n, 3) array.  NumPy's axis-0 reduction of a narrow array runs an inner loop of
+    length 3 (3.7 s for 85 M vertices); column by column in slices on a few threads it takes 0.1 s, same values."""
+    n = len(vertices)
+    if n < (1 << 20):
+        return vertices.min(axis=0), vertices.max(axis=0)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    nthreads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))
+    edges = np.linspace(0, n, 4 * nthreads + 1).astype(np.int64)
+
+    def part(k):
+        c = vertices[edges[k]:edges[k + 1]]
+        return [c[:, j].min() for j in range(3)], [c[:, j].max() for j in range(3)]
+    with ThreadPoolExecutor(nthreads) as pool:
+        parts = list(pool.map(part, range(len(edges) - 1)))
+    lo = np.min(np.array([p[0] for p in parts], dtype=vertices.dtype), axis=0)
+    hi = np.max(np.array([p[1] for p in parts], dtype=vertices.dtype), axis=0)
+    return lo, hi
+
+
 def world_coords_for(vertices):
     """Fixed-point frame of a mesh (chroma/gpu/bvh.py:43-48)."""
-    world_origin = vertices.min(axis=0)
-    world_scale = np.max(vertices.max(axis=0) - world_origin) / np.float32(2 ** 16 - 2)
+    world_origin, upper = _bounds(vertices)
+    world_scale = np.max(upper - world_origin) / np.float32(2 ** 16 - 2)
     return WorldCoords(world_origin=world_origin, world_scale=world_scale)
 
 

@@ -3357,6 +3357,28 @@ static int upload(chroma_geometry *g, const T *host, size_t count, const T **dev
     return CHROMA_OK;
 }
 
+// chroma_geometry_create's two derived arrays, made on the device from what has just been uploaded
+__global__ void k_traversal_nodes(const uint4 *nodes, uint32_t nnodes, const uint32_t *tri_to_dev, uint32_t ntriangles, uint4 *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnodes) return;
+    uint4 n = nodes[i];
+    if ((n.w >> CHROMA_CHILD_BITS) == 0) { const uint32_t t = n.w & ~CHROMA_NCHILD_MASK; n.w = t < ntriangles ? tri_to_dev[t] : n.w; }
+    out[i] = n;
+}
+__global__ void k_triangle_records(const float *vertices, const uint32_t *triangles, const uint32_t *codes, const uint32_t *rank,
+                                   const uint32_t *dev_to_tri, uint32_t nrecords, float4 *tri)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nrecords) return;
+    const uint32_t t = dev_to_tri[k];
+    const uint32_t extra[3] = {codes[t], t, rank[t]};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float *vv = vertices + 3 * (size_t)triangles[3 * (size_t)t + c];
+        tri[(size_t)TRI_STRIDE * k + c] = make_float4(vv[0], vv[1], vv[2], __uint_as_float(extra[c]));
+    }
+}
 // Worst-case number of simultaneously live stack entries of the depth-first walk in
 // intersect_mesh for this tree (every box test succeeding).  Children always have larger
 // indices than their parent (layers are stored root first), so one backward sweep suffices.
@@ -4013,7 +4035,7 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
     { chroma_host::WordBuffer().swap(wt.wnodes); }
     UP(tri_to_dev, tri_to_dev, d->ntriangles);
     UP(dev_to_tri, dev_to_tri, nrecords);
-    // traversal copy of the nodes: leaf child -> device triangle index
+    // traversal copy of the nodes: leaf child -> device triangle index (a pass over the array uploaded above)
     {
         void *dn = nullptr;
         size_t bytes = (size_t)d->nnodes * 16;
@@ -4021,24 +4043,16 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
         if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "hipMalloc(%zu) for nodes: %s", bytes, hipGetErrorString(e)); }
         g->allocations.push_back(dn);
         g->device_bytes += bytes;
-        const size_t CH = 1u << 22;
-        std::vector<uint32_t> stage(std::min((size_t)d->nnodes, CH) * 4);
-        for (size_t n0 = 0; n0 < d->nnodes; n0 += CH) {
-            size_t n1 = std::min((size_t)d->nnodes, n0 + CH);
-            memcpy(stage.data(), d->nodes + 4 * n0, (n1 - n0) * 16);
-            chroma_host::parallel_for(n1 - n0, [&](size_t lo, size_t hi) {
-                for (size_t i = lo; i < hi; i++) {
-                    uint32_t w = stage[4 * i + 3];
-                    if ((w >> CHROMA_CHILD_BITS) == 0) stage[4 * i + 3] = tri_to_dev[w & ~CHROMA_NCHILD_MASK];
-                }
-            });
-            e = hipMemcpy((char *)dn + n0 * 16, stage.data(), (n1 - n0) * 16, hipMemcpyHostToDevice);
-            if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "node upload: %s", hipGetErrorString(e)); }
-        }
+        hipLaunchKernelGGL(k_traversal_nodes, dim3((unsigned)((d->nnodes + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)g->d_nodes_api, (uint32_t)d->nnodes,
+                           v.tri_to_dev, d->ntriangles, (uint4 *)dn);
         v.nodes = (const uint4 *)dn;
     }
     phase("wide nodes + traversal copy");
-    // 48-byte triangle records in device order, staged in chunks
+    // API-visible copies of the mesh arrays (GPUGeometry.vertices/.triangles/.material_codes/.colors)
+    { const float *p; if ((rc = upload(g, d->vertices, (size_t)d->nvertices * 3, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_vertices = (void *)p; }
+    { const uint32_t *p; if ((rc = upload(g, d->triangles, (size_t)d->ntriangles * 3, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_triangles = (void *)p; }
+    { const uint32_t *p; if ((rc = upload(g, d->material_codes, d->ntriangles, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_material_codes = (void *)p; }
+    // 48-byte triangle records in device order: gathered on the device from those arrays (+ the ranks, uploaded for this only)
     {
         void *dtri = nullptr;
         size_t bytes = nrecords * (16 * TRI_STRIDE);
@@ -4046,32 +4060,21 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
         if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "hipMalloc(%zu) for triangle records: %s", bytes, hipGetErrorString(e)); }
         g->allocations.push_back(dtri);
         g->device_bytes += bytes;
-        const size_t CH = 1u << 22;
-        std::vector<float> stage(std::min(nrecords, CH) * (4 * TRI_STRIDE), 0.0f);
-        for (size_t t0 = 0; t0 < nrecords; t0 += CH) {
-            size_t t1 = std::min(nrecords, t0 + CH);
-            chroma_host::parallel_for(t1 - t0, [&](size_t lo, size_t hi) {
-                for (size_t k = t0 + lo; k < t0 + hi; k++) {
-                    size_t t = dev_to_tri[k];
-                    float *r = stage.data() + (k - t0) * (4 * TRI_STRIDE);
-                    for (int c = 0; c < 3; c++) {
-                        const float *vv = d->vertices + 3 * (size_t)d->triangles[3 * t + c];
-                        r[4 * c] = vv[0]; r[4 * c + 1] = vv[1]; r[4 * c + 2] = vv[2];
-                    }
-                    uint32_t code = d->material_codes[t], tid = (uint32_t)t, rank = tri_rank[t];
-                    memcpy(&r[3], &code, 4); memcpy(&r[7], &tid, 4); memcpy(&r[11], &rank, 4);
-                }
-            });
-            e = hipMemcpy((char *)dtri + t0 * (16 * TRI_STRIDE), stage.data(), (t1 - t0) * (16 * TRI_STRIDE), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "triangle upload: %s", hipGetErrorString(e)); }
+        uint32_t *d_rank = nullptr;
+        e = hipMalloc((void **)&d_rank, std::max<size_t>(d->ntriangles, 1) * 4);
+        if (e != hipSuccess) { chroma_geometry_destroy(g); return set_error((int)e, "hipMalloc for triangle ranks: %s", hipGetErrorString(e)); }
+        rc = chroma_internal_htod(ctx, d_rank, tri_rank, (size_t)d->ntriangles * 4);
+        if (rc == CHROMA_OK) {
+            hipLaunchKernelGGL(k_triangle_records, dim3((unsigned)((nrecords + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)g->d_vertices, (const uint32_t *)g->d_triangles,
+                               (const uint32_t *)g->d_material_codes, d_rank, v.dev_to_tri, (uint32_t)nrecords, (float4 *)dtri);
+            e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = set_error((int)e, "triangle records: %s", hipGetErrorString(e));
         }
+        hipFree(d_rank);
+        if (rc != CHROMA_OK) { chroma_geometry_destroy(g); return rc; }
         v.tri = (const float4 *)dtri;
     }
     phase("triangle records");
-    // API-visible copies of the mesh arrays (GPUGeometry.vertices/.triangles/.material_codes/.colors)
-    { const float *p; if ((rc = upload(g, d->vertices, (size_t)d->nvertices * 3, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_vertices = (void *)p; }
-    { const uint32_t *p; if ((rc = upload(g, d->triangles, (size_t)d->ntriangles * 3, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_triangles = (void *)p; }
-    { const uint32_t *p; if ((rc = upload(g, d->material_codes, d->ntriangles, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_material_codes = (void *)p; }
     { const uint32_t *p; if ((rc = upload(g, d->colors, d->colors ? d->ntriangles : 0, &p)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; } g->d_colors = (void *)p; }
     UP(solid_id_map, d->solid_id_map, d->solid_id_map ? d->ntriangles : 0);
     size_t wn = d->wavelength_n;

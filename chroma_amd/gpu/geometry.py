@@ -38,6 +38,8 @@ class PackedGeometry(object):
         self.desc = _lib.GeometryDesc()
 
     def put(self, name, array, dtype):
+        if isinstance(array, np.ndarray) and array.dtype == np.int32 and dtype == np.uint32 and array.flags['C_CONTIGUOUS']:
+            array = array.view(np.uint32)             # (the same bits: no 2-GB copy of a detector's triangle indices)
         a = np.ascontiguousarray(array, dtype=dtype)
         self.arrays[name] = a
         setattr(self.desc, name, a.ctypes.data if a.size else None)
@@ -125,9 +127,14 @@ def pack_geometry(geometry, wavelengths=None, times=None):
     pk.put('triangles', mesh.triangles, np.uint32)
     d.nvertices, d.ntriangles = len(mesh.vertices), len(mesh.triangles)
     # 8-bit two's-complement indices, -1 = no surface (chroma/gpu/geometry.py:203-205)
-    codes = (((geometry.inner_material_index.astype(np.int64) & 0xff) << 24) |
-             ((geometry.outer_material_index.astype(np.int64) & 0xff) << 16) |
-             ((geometry.surface_index.astype(np.int64) & 0xff) << 8)).astype(np.uint32)
+    def byte_of(index, shift):          # low byte of a (possibly negative) index, in place in one 32-bit temporary
+        b = np.asarray(index).astype(np.uint32)
+        b &= np.uint32(0xff)
+        b <<= np.uint32(shift)
+        return b
+    codes = byte_of(geometry.inner_material_index, 24)
+    codes |= byte_of(geometry.outer_material_index, 16)
+    codes |= byte_of(geometry.surface_index, 8)
     pk.put('material_codes', codes, np.uint32)
     pk.put('solid_id_map', geometry.solid_id, np.uint32)
     pk.put('colors', geometry.colors, np.uint32)
