@@ -355,10 +355,10 @@ int chroma_bvh_build_device(chroma_ctx *ctx, const float *vertices, uint32_t nve
         hipLaunchKernelGGL(k_bvh_collapse, dim3(blocks_for(hi - lo)), dim3(256), 0, stream, d_nodes, lo, hi);
     }
     hipError_t e = hipGetLastError();
-    res->nodes.resize(total);
-    if (e == hipSuccess) e = hipMemcpyAsync(res->nodes.data(), d_nodes, total * sizeof(uint4), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) { delete res; return chroma_internal_set_error((int)e, "chroma_bvh_build_device: %s", hipGetErrorString(e)); }
+    res->nodes.resize(total);
+    { const int rc_ = chroma_internal_dtoh(ctx, res->nodes.data(), d_nodes, total * sizeof(uint4)); if (rc_ != CHROMA_OK) { delete res; return rc_; } }
     lap.lap("concatenate + collapse + download");
     *handle = res;
     if (nnodes) *nnodes = total;

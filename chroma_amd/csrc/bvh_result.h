@@ -3,11 +3,12 @@
 #pragma once
 #include <stdint.h>
 #include <vector>
+#include "uninit_vector.h"
 
 namespace chroma_host {
 struct Node { uint32_t x, y, z, w; };
 struct BvhResult {
-    std::vector<Node> nodes;
+    uninit_vector<Node> nodes;
     std::vector<uint64_t> layer_bounds;   // nlayers + 1 entries
 };
 }  // namespace chroma_host

@@ -2,11 +2,9 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
-#include <memory>
-#include <new>
 #include <string>
-#include <utility>
 #include <vector>
+#include "uninit_vector.h"
 
 namespace chroma_host {
 
@@ -22,15 +20,7 @@ enum { WIDE_TOPOLOGY_COLLAPSE = 0,     // the reference tree with children pulle
                                        // partitions, the least-area collapse over the whole tree, breadth-first node order -- what the device
                                        // builder (csrc/wide_device.hip) makes, bit for bit.  THE DEFAULT.
 
-// a vector whose resize() leaves new elements uninitialised: 4 GB of wide nodes are written once, by the builder, not
-// zeroed first by one thread (assign / resize(n, value) still fill)
-template <class T> struct default_init_allocator : std::allocator<T> {
-    template <class U> struct rebind { using other = default_init_allocator<U>; };
-    using std::allocator<T>::allocator;
-    template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
-    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
-};
-typedef std::vector<uint32_t, default_init_allocator<uint32_t>> WordBuffer;
+typedef uninit_vector<uint32_t> WordBuffer;       // (4 GB of wide nodes at C3: see uninit_vector.h)
 
 struct WideTree {
     WordBuffer wnodes;       // nwide * 8 entries of 4 words: x, y, z boxes, w = child (see above)

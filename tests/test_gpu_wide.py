@@ -113,3 +113,30 @@ def test_propagation_over_the_device_tree_matches_the_oracle(ctx, oracle_mod):
     for field in ('pos', 'dir', 'pol', 'wavelengths', 't', 'flags', 'last_hit_triangles'):
         assert np.array_equal(getattr(got, field).view(np.uint32), getattr(want, field).view(np.uint32)), field
     assert np.array_equal(gp.rng_counters.get(), counters)
+
+
+def test_stack_need_by_passes_on_the_device_is_the_backward_sweep(ctx):
+    """chroma_geometry_create works out the reference walk's stack need by passes over the uploaded node array until
+    nothing changes; the value is the one backward sweep of the definition gives (mesh.h:68-110: at a node every inner
+    child is pushed, the last one is walked first)."""
+    from chroma_amd import demo, gpu, make
+    from chroma_amd.loader import create_geometry_from_obj
+
+    def sphere():
+        return make.sphere(50.0, 60)
+    for build in (demo.tiny, sphere):
+        g = create_geometry_from_obj(build())
+        w = np.ascontiguousarray(g.bvh.nodes).view(np.uint32).reshape(-1, 4)[:, 3]
+        nchild, first = (w >> 28).astype(np.int64), (w & 0x0FFFFFFF).astype(np.int64)
+        need = np.zeros(len(w), dtype=np.int64)
+        for i in range(len(w) - 1, -1, -1):
+            if nchild[i] == 0:
+                continue
+            rank = best = 0
+            for c in range(first[i], first[i] + nchild[i]):
+                if nchild[c]:
+                    best = max(best, rank + need[c])
+                    rank += 1
+            need[i] = max(best, rank)
+        gg = gpu.GPUGeometry(g)
+        assert gg.stack_need() == max(1, int(need[0])), build.__name__
