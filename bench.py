@@ -460,7 +460,7 @@ def main():
         physics['traffic_over_algorithmic'] = per_step * stats.get('physics_launches', 0) / phys_bytes_total
 
     # ---- the same batch with its photons in GENERATION order (round 2's input; one extra batch, not part of `value`)
-    unsorted_rate = None
+    unsorted_rate = unsorted_asis_rate = None
     if world == 1 and SORT_DIRECTIONS and not os.environ.get('CHROMA_BENCH_NO_EXACT'):
         b = buffers[0]
         b.id_base = (20_001 * world + rank) * nphotons
@@ -468,10 +468,23 @@ def main():
         _lib.check(lib.chroma_generate_bomb(ctx.handle, ctypes.byref(b.struct), nphotons, ENGINE_SEED, b.id_base, pos, wl_lo, wl_hi))
         ctx.synchronize()
         t0 = time.perf_counter()
-        run_step(b, False, {})
+        st_u = {}
+        run_step(b, False, st_u)
         ctx.synchronize()
         unsorted_rate = nphotons / (time.perf_counter() - t0)
         log('photons in generation order (not sorted by direction): %.3g photons/s on one batch' % unsorted_rate)
+        if os.environ.get('CHROMA_BENCH_AUTOSORT'):
+            # (A/B of chroma_set_autosort: the same batch once more, ordered by the engine itself -- an index sort + gather)
+            _lib.check(lib.chroma_generate_bomb(ctx.handle, ctypes.byref(b.struct), nphotons, ENGINE_SEED, b.id_base, pos, wl_lo, wl_hi))
+            ctx.set_autosort('auto')
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            run_step(b, False, st_u)
+            ctx.synchronize()
+            unsorted_asis_rate = nphotons / (time.perf_counter() - t0)
+            ctx.set_autosort('off')
+            log('  the same with chroma_set_autosort(auto): %.3g photons/s (%d photons taken up in direction order by the engine)' % (
+                unsorted_asis_rate, st_u.get('reordered', 0)))
 
     cpu_baseline = None
     if run_cpu:
@@ -537,7 +550,7 @@ def main():
                                   'propagate benchmark prepares them before its clock starts (chroma/benchmark.py:80-82)' if SORT_DIRECTIONS else '; photons in generation order (unsorted)'),
                        'target_photons_per_s_per_gpu': 2.5e6, 'vs_target': value / world / 2.5e6,
                        'steps_per_photon': steps_pp, 'nodes_per_step': nodes_ps, 'triangle_tests_per_step': tris_ps,
-                       'exact_walk_photons_per_s': exact_rate, 'generation_order_photons_per_s': unsorted_rate,
+                       'exact_walk_photons_per_s': exact_rate, 'generation_order_photons_per_s': unsorted_rate, 'generation_order_autosort_photons_per_s': unsorted_asis_rate,
                        'geometry_build_s': t_build, 'geometry_cached': geometry_cached, 'geometry_upload_s': t_upload,
                        'reduction': ('none: one GPU' if world == 1 and not os.environ.get('CHROMA_BENCH_COMM') else
                                      'library RCCL (chroma_allreduce_hits, in place on the device arrays)' if lib_comm else

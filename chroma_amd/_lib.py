@@ -72,7 +72,8 @@ class PropagateStats(Structure):
                 ('launches', c_uint64), ('stack_overflows', c_uint64), ('kernel_ms', c_double),
                 ('raycast_ms', c_double), ('raycast_launches', c_uint64), ('stack_spills', c_uint64),
                 ('physics_ms', c_double), ('physics_launches', c_uint64), ('packet_ms', c_double), ('packet_launches', c_uint64),
-                ('packet_rays', c_uint64), ('packet_nodes_visited', c_uint64), ('packet_triangles_tested', c_uint64)]
+                ('packet_rays', c_uint64), ('packet_nodes_visited', c_uint64), ('packet_triangles_tested', c_uint64),
+                ('reordered', c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -165,6 +166,7 @@ SIGNATURES = {
     'chroma_set_walk': (c_int32, [c_void_p, c_int32]),
     'chroma_set_tail': (c_int32, [c_void_p, c_int32]),
     'chroma_set_packet': (c_int32, [c_void_p, c_int32]),
+    'chroma_set_autosort': (c_int32, [c_void_p, c_int32]),
 }
 
 _lib = None

@@ -438,3 +438,50 @@ extern "C" int chroma_photons_sort_direction(chroma_ctx *ctx, const chroma_photo
     DEV_TRY(hipStreamSynchronize(stream));
     return CHROMA_OK;
 }
+
+// ---- the order in which chroma_propagate takes up the photons of a POINT-LIKE source that arrive in no particular order ----
+// (chroma_hip.hip: propagate_order).  A 16-bit cell of the direction on an octahedral map of the sphere (no arc functions; a
+// heuristic that steers speed only -- results are stored by photon id and drawn from per-photon streams), Morton-interleaved
+// so that neighbouring cells are neighbours in the order; a stable two-pass radix sort of (cell, photon).  The scratch
+// arrays come from the context's pool, so a second call allocates nothing.
+namespace {
+__global__ void k_order_codes(const float *dir, uint32_t n, uint32_t *codes, uint32_t *ids)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = dir[3 * (size_t)i], y = dir[3 * (size_t)i + 1], z = dir[3 * (size_t)i + 2];
+    const float s = fabsf(x) + fabsf(y) + fabsf(z);
+    float u = s > 0.0f ? x / s : 0.0f, v = s > 0.0f ? y / s : 0.0f;
+    if (z < 0.0f) { const float uu = (1.0f - fabsf(v)) * (u < 0.0f ? -1.0f : 1.0f), vv = (1.0f - fabsf(u)) * (v < 0.0f ? -1.0f : 1.0f); u = uu; v = vv; }
+    const uint32_t iu = (uint32_t)fminf(255.0f, fmaxf(0.0f, (u * 0.5f + 0.5f) * 256.0f)), iv = (uint32_t)fminf(255.0f, fmaxf(0.0f, (v * 0.5f + 0.5f) * 256.0f));
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) m |= ((iu & (1u << b)) << b) | ((iv & (1u << b)) << (b + 1));
+    codes[i] = m;
+    ids[i] = i;
+}
+}  // namespace
+
+extern "C" int chroma_internal_direction_order(chroma_ctx *ctx, const float *d_dir, uint32_t n, uint32_t *d_order)
+{
+    hipStream_t stream = chroma_internal_stream(ctx);
+    void *codes = nullptr, *sorted = nullptr, *ids = nullptr, *tmp = nullptr;
+    int rc = chroma_malloc(ctx, (size_t)n * 4, &codes);
+    if (rc == CHROMA_OK) rc = chroma_malloc(ctx, (size_t)n * 4, &sorted);
+    if (rc == CHROMA_OK) rc = chroma_malloc(ctx, (size_t)n * 4, &ids);
+    size_t tmp_bytes = 0;
+    hipError_t e = hipSuccess;
+    if (rc == CHROMA_OK) {
+        e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (uint32_t *)codes, (uint32_t *)sorted, (uint32_t *)ids, d_order, (int)n, 0, 16, stream);
+        if (e == hipSuccess) rc = chroma_malloc(ctx, tmp_bytes, &tmp);
+    }
+    if (rc == CHROMA_OK && e == hipSuccess) {
+        hipLaunchKernelGGL(k_order_codes, dim3(blocks_for(n)), dim3(256), 0, stream, d_dir, n, (uint32_t *)codes, (uint32_t *)ids);
+        e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (uint32_t *)codes, (uint32_t *)sorted, (uint32_t *)ids, d_order, (int)n, 0, 16, stream);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    chroma_free(ctx, codes); chroma_free(ctx, sorted); chroma_free(ctx, ids); chroma_free(ctx, tmp);      // (parked behind the stream's work)
+    if (rc != CHROMA_OK) return rc;
+    if (e != hipSuccess) return chroma_internal_set_error((int)e, "direction order: %s", hipGetErrorString(e));
+    return CHROMA_OK;
+}

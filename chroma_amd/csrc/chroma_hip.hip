@@ -103,6 +103,7 @@ struct chroma_ctx {
     int ray_chunk = 256, coop_chunk = 64;  // rays a persistent wave takes from the queue per atomic (big batches)
     int fused_tail = 1;                    // 0 (CHROMA_TAIL=split): the last photons also take one launch set per step
     int split_tail = 1;                    // 0 (CHROMA_TAIL=fused): chroma_propagate launches the fused kernel only, as the reference does
+    int autosort_mode = 0;                 // the order a large call takes its photons up in: 0 as they come (default: the index sort + gather cost more than they gain, profiles/r03/ab_autosort.txt), 1 by direction cell, 2 decided by a probe (propagate_order)
     int packet_mode = 0;                   // k_raycast_packet for the first step: 0 never (default: it is not faster, profiles/r03/ab_packet_first_step.txt), 1 always, 2 when the photons are coherent (CHROMA_PACKET=off|on|auto)
     int wide_walk = CHROMA_WALK_QUAD;      // CHROMA_WALK_*: reference tree | wide tree with 1, 8 or 4 (default) lanes per ray
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
@@ -2453,8 +2454,9 @@ k_physics_deal(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, u
 // thereby untouched (propagate.cu:258).
 __global__ __launch_bounds__(PHYS_BLOCK) void
 k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t n, uint32_t ncopies, uint32_t true_n, float4 *rays,
-               uint32_t *coherence)
+               uint32_t *coherence, const uint32_t *order = nullptr)
 {
+    // (`order`: take the photons up in this order instead of by index -- propagate_order below; ncopies == 1 then)
     // (`rays`: also the ray records of the first step -- the first launch of a call always re-normalises)
     // (`coherence`: [0] += waves whose photons share an origin and lie within a cone of 50 mrad, [1] += waves looked at:
     //  what decides between k_raycast_packet and k_raycast_quad for the first step.  A heuristic: it steers speed only.)
@@ -2465,7 +2467,7 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
         bool take = false;
         uint32_t photon_id = 0, flags = 0;
         if (j < n) {
-            photon_id = (uint32_t)(j / ncopies) + (uint32_t)(j % ncopies) * true_n;
+            photon_id = order ? order[j] : (uint32_t)(j / ncopies) + (uint32_t)(j % ncopies) * true_n;
             flags = pv.flags[photon_id];
             take = (flags & CHROMA_TERMINAL_MASK) == 0;
         }
@@ -3596,6 +3598,7 @@ int chroma_init(int device, chroma_ctx **out)
                            : !strcmp(e, "coop") ? CHROMA_WALK_COOP : !strcmp(e, "pair") ? CHROMA_WALK_PAIR
                            : (!strcmp(e, "literal") || !strcmp(e, "exact")) ? CHROMA_WALK_LITERAL : CHROMA_WALK_QUAD;
         if (const char *e = getenv("CHROMA_PACKET")) ctx->packet_mode = !strcmp(e, "on") ? 1 : !strcmp(e, "auto") ? 2 : 0;
+        if (const char *e = getenv("CHROMA_AUTOSORT")) ctx->autosort_mode = !strcmp(e, "on") || !strcmp(e, "1") ? 1 : !strcmp(e, "off") || !strcmp(e, "0") ? 0 : 2;
         if (const char *e = getenv("CHROMA_RAY_CHUNK")) ctx->ray_chunk = std::max(64, atoi(e));
         if (const char *e = getenv("CHROMA_COOP_CHUNK")) ctx->coop_chunk = std::max(8, atoi(e));
         if (const char *e = getenv("CHROMA_TAIL")) {      // coop (default) | split | fused (the lane-per-photon k_propagate)
@@ -4451,6 +4454,14 @@ int chroma_set_packet(chroma_ctx *ctx, int32_t mode)
     return CHROMA_OK;
 }
 
+int chroma_set_autosort(chroma_ctx *ctx, int32_t mode)
+{
+    if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
+    if (mode < 0 || mode > 2) return set_error(CHROMA_ERR_INVALID, "unknown autosort mode %d", mode);
+    ctx->autosort_mode = mode;
+    return CHROMA_OK;
+}
+
 int chroma_set_tail(chroma_ctx *ctx, int32_t mode)
 {
     if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
@@ -4458,6 +4469,70 @@ int chroma_set_tail(chroma_ctx *ctx, int32_t mode)
         return set_error(CHROMA_ERR_INVALID, "unknown tail mode %d", mode);
     ctx->split_tail = mode != CHROMA_TAIL_FUSED;
     ctx->fused_tail = mode == CHROMA_TAIL_COOP;
+    return CHROMA_OK;
+}
+
+// ---- a point-like source in no particular order ----------------------------------------------------------------------
+// The first launches of a call take a third of a C3 step, and how long they take depends on whether the rays of a wave walk
+// the same part of the tree: 29 ms with the photons in direction order against 39 ms in generation order (item 4 of round 3;
+// the reference's own benchmark sorts its photons before the clock starts, chroma/benchmark.py:80-82).  A caller's photons
+// are not sorted.  Nothing in the RESULT depends on the order in which the working set takes the photons up -- streams are
+// keyed by photon id, results are stored by photon id -- so chroma_propagate chooses that order itself when it pays: a sample
+// of the input says "one origin, directions all over the place" (a bomb, a calibration source), and the call is large.  Then
+// the photons are ordered by a 16-bit direction cell (bvh_device.hip) and k_load_working gathers through that order.
+// Photons that already are coherent, or that come from many places (tracks: their order is the caller's locality), are
+// taken as they come.  chroma_set_autosort / CHROMA_AUTOSORT=off|on|auto: never (default), for every large call, by the probe.
+// MEASURED (profiles/r03/ab_autosort.txt, C3, 1e8 photons of a bomb in generation order): 164 ms per batch with the engine's
+// ordering against 128 ms with the photons taken as they come (and 114 ms when the caller hands them over sorted): the codes,
+// the radix sort of 1e8 pairs and above all k_load_working GATHERING ten arrays through a random permutation (12-byte reads
+// that each pull a 64-byte sector) cost 50 ms to win 15.  So the switch is OFF by default -- an opt-in with its parity test,
+// like the packet kernel -- and the sorted order stays what the reference makes it: the caller's preparation
+// (chroma_photons_sort_direction / GPUPhotons.sort_by_direction, outside the clock as in chroma/benchmark.py:80-82).
+__global__ void k_order_probe(PhotonView pv, uint64_t n, uint32_t nsamples, uint32_t *out /* [0] waves of one origin, [1] of those: coherent, [2] waves looked at */)
+{
+    const uint32_t s = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    if (s >= nsamples) return;
+    const uint64_t start = (n / nsamples) * s / WAVE * WAVE;
+    const uint64_t i = start + lane_id();
+    if (start + WAVE > n) return;
+    const v3 pos = load3(pv.pos, i), dir = load3(pv.dir, i);
+    const float px = __shfl(pos.x, 0), py = __shfl(pos.y, 0), pz = __shfl(pos.z, 0);
+    const float qx = __shfl(dir.x, 0), qy = __shfl(dir.y, 0), qz = __shfl(dir.z, 0);
+    const float d2 = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z, q2 = qx * qx + qy * qy + qz * qz;
+    const float c = dir.x * qx + dir.y * qy + dir.z * qz;
+    const bool same = fabsf(pos.x - px) + fabsf(pos.y - py) + fabsf(pos.z - pz) < 1.0f;
+    const bool cone = c > 0.0f && c * c > 0.9975f * d2 * q2;
+    const unsigned long long all_same = __ballot(same), all_cone = __ballot(cone);
+    if (lane_id() == 0) {
+        atomicAdd(out + 2, 1u);
+        if (all_same == ~0ull) { atomicAdd(out, 1u); if (all_cone == ~0ull) atomicAdd(out + 1, 1u); }
+    }
+}
+#ifndef AUTOSORT_MIN
+#define AUTOSORT_MIN (1u << 21)
+#endif
+// *d_order: nullptr (take the photons as they come) or a chroma_malloc'ed permutation the caller frees after k_load_working
+static int propagate_order(chroma_ctx *ctx, const PhotonView &pv, uint64_t nphotons, uint32_t ncopies, uint32_t **d_order)
+{
+    *d_order = nullptr;
+    const int mode = ctx->autosort_mode;
+    if (mode == 0 || ncopies != 1 || nphotons < AUTOSORT_MIN) return CHROMA_OK;
+    if (mode == 2) {
+        const uint32_t nsamples = 1024;
+        HIP_TRY(hipMemsetAsync(ctx->d_words + 8, 0, 12, ctx->stream));
+        hipLaunchKernelGGL(k_order_probe, dim3(nsamples / 4), dim3(256), 0, ctx->stream, pv, nphotons, nsamples, ctx->d_words + 8);
+        uint32_t h[3];
+        HIP_TRY(hipMemcpyAsync(h, ctx->d_words + 8, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        // one origin in nine sampled waves of ten, and fewer than half of them already coherent
+        if (h[2] == 0 || 10ull * h[0] < 9ull * h[2] || 2ull * h[1] >= h[0]) return CHROMA_OK;
+    }
+    void *p = nullptr;
+    int rc = chroma_malloc(ctx, (size_t)nphotons * 4, &p);
+    if (rc != CHROMA_OK) return rc;
+    rc = chroma_internal_direction_order(ctx, pv.dir, (uint32_t)nphotons, (uint32_t *)p);
+    if (rc != CHROMA_OK) { chroma_free(ctx, p); return rc; }
+    *d_order = (uint32_t *)p;
     return CHROMA_OK;
 }
 
@@ -4480,6 +4555,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     double kernel_ms = 0.0, raycast_ms = 0.0, physics_ms = 0.0, packet_ms = 0.0;
     uint64_t launches = 0, raycast_launches = 0, physics_launches = 0, packet_launches = 0;
     bool packet_offered = false;
+    uint64_t reordered = 0;
     // Launch policy of the reference (chroma/gpu/photon.py:225-252): one step per launch while many
     // photons are alive, and ONE launch for all remaining steps once fewer than 64*16*8 are left (or
     // with weights).  A launch re-normalises dir/pol when it loads a photon (propagate.cu:248,250), so
@@ -4502,9 +4578,13 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
             const bool probe = step_uses_quad_walk(ctx, geom) && ctx->packet_mode != 0 && geom->wide_stack_need <= PACKET_STACK;
             packet_offered = probe;
             HIP_TRY(hipMemsetAsync(ctx->d_words + 4, 0, 12, ctx->stream));          // [4] use_packet, [5] coherent waves, [6] waves
+            uint32_t *d_order = nullptr;
+            if (step_uses_quad_walk(ctx, geom)) { rc = propagate_order(ctx, pv, nphotons, ncopies, &d_order); if (rc) return rc; }
             hipLaunchKernelGGL(k_load_working, dim3(blocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, in_q, work_in,
                                (uint64_t)nphotons, ncopies, (uint32_t)(nphotons / ncopies),
-                               step_uses_quad_walk(ctx, geom) ? ctx->rays : nullptr, (probe && ctx->packet_mode == 2) ? ctx->d_words + 5 : nullptr);
+                               step_uses_quad_walk(ctx, geom) ? ctx->rays : nullptr, (probe && ctx->packet_mode == 2) ? ctx->d_words + 5 : nullptr,
+                               (const uint32_t *)d_order);
+            if (d_order) { chroma_free(ctx, d_order); reordered = nphotons; }      // (parked until the stream has passed this point)
             if (probe)
                 hipLaunchKernelGGL(k_packet_decide, dim3(1), dim3(1), 0, ctx->stream, ctx->d_words + 5, ctx->d_words + 4, (uint64_t)nphotons, ctx->packet_mode);
         }
@@ -4638,6 +4718,7 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         stats->physics_launches += physics_launches;
         stats->packet_ms += packet_ms;
         stats->packet_launches += packet_launches;
+        stats->reordered += reordered;
         if (stats->stack_overflows) return set_error(CHROMA_ERR_STACK, "traversal stack overflowed for %llu rays", (unsigned long long)stats->stack_overflows);
     } else {
         chroma_propagate_stats tmp; memset(&tmp, 0, sizeof tmp);

@@ -12,4 +12,6 @@ int chroma_internal_set_error(int code, const char *fmt, ...);      // returns `
 // both return when the data has arrived
 int chroma_internal_dtoh(chroma_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes);
 int chroma_internal_htod(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes);
+// (bvh_device.hip) d_order[n] = the photons 0..n-1 ordered by a 16-bit cell of their direction; queued on the context's stream
+int chroma_internal_direction_order(chroma_ctx *ctx, const float *d_dir, uint32_t n, uint32_t *d_order);
 }

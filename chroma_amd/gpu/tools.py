@@ -115,6 +115,14 @@ class Context(object):
         photons themselves."""
         _lib.check(self._lib.chroma_set_packet(self.handle, {'off': 0, 'on': 1, 'auto': 2}[mode]))
 
+    def set_autosort(self, mode):
+        """'off' (default), 'auto' or 'on': whether a large propagate call takes its photons up in direction order by
+        itself (an index sort on the device; same results photon by photon).  'auto' looks at a sample of the input: one
+        origin and scattered directions are ordered, coherent photons and photons from many places are not.  Measured
+        SLOWER than taking a bomb as it comes (the gather through the order costs more than the coherent first launches
+        win): an opt-in experiment -- sort_by_direction() before the clock is what pays, as in chroma/benchmark.py:80-82."""
+        _lib.check(self._lib.chroma_set_autosort(self.handle, {'off': 0, 'on': 1, 'auto': 2}[mode]))
+
     def set_tail(self, mode):
         """'coop' (default), 'split' or 'fused': how propagate() finishes -- or, with 'fused', runs -- a batch."""
         _lib.check(self._lib.chroma_set_tail(self.handle, {'coop': 0, 'split': 1, 'fused': 2}[mode]))

@@ -172,6 +172,7 @@ typedef struct chroma_propagate_stats {
                                     raycast_ms / raycast_launches then are k_raycast_quad's alone               */
     uint64_t packet_launches;
     uint64_t packet_rays, packet_nodes_visited, packet_triangles_tested;   /* counting mode: the packet kernel's share */
+    uint64_t reordered;          /* photons of calls that took them up in direction order (chroma_set_autosort) */
 } chroma_propagate_stats;
 
 const char *chroma_last_error(void);
@@ -480,6 +481,22 @@ int chroma_set_walk(chroma_ctx *ctx, int32_t mode);
 #define CHROMA_PACKET_ON   1
 #define CHROMA_PACKET_AUTO 2
 int chroma_set_packet(chroma_ctx *ctx, int32_t mode);
+
+/* The ORDER in which a large chroma_propagate call (>= 2^21 photons, ncopies 1, default walk) takes its photons up.  Nothing
+ * in the result depends on it (streams are keyed by photon id, results stored by photon id), the time does: rays of
+ * neighbouring slots that walk the same part of the tree make the first launches of a call a quarter faster -- which is why
+ * the reference's benchmark sorts its photons with tools.argsort_direction before the clock starts (chroma/benchmark.py:80-82).
+ * AUTO: a sample of the input decides -- one origin and directions all over the place (a bomb or a calibration
+ * source in generation order) are ordered by a 16-bit direction cell on the device (one radix sort of indices; the photon
+ * arrays stay as they are); photons that are coherent already, or that come from many places, are taken as they come.
+ * ON: every large call.  OFF (default): never -- measured at 1e8 photons on the 29k-PMT detector the index sort and the
+ * gather through it cost 50 ms to win 15 (profiles/r03/ab_autosort.txt), so ordering stays the caller's preparation
+ * (chroma_photons_sort_direction, as the reference's benchmark does it before its clock starts).
+ * Env CHROMA_AUTOSORT=off|on|auto.  stats.reordered counts the photons so taken. */
+#define CHROMA_AUTOSORT_OFF  0
+#define CHROMA_AUTOSORT_ON   1
+#define CHROMA_AUTOSORT_AUTO 2
+int chroma_set_autosort(chroma_ctx *ctx, int32_t mode);
 
 /* How chroma_propagate finishes a batch and, with FUSED, how it runs it at all (same results; for
  * tests and benchmarks).  COOP: per-step launch sets, then ONE cooperative launch for all remaining
