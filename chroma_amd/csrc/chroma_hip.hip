@@ -127,6 +127,10 @@ struct chroma_ctx {
     static constexpr size_t STAGE_BYTES = 64u << 20;
     void *stage[STAGE_N] = {nullptr, nullptr, nullptr};
     hipEvent_t stage_ev[STAGE_N] = {nullptr, nullptr, nullptr};
+    // the same ring for device -> host copies, with its own lock: a hit download does not queue behind the next batch's upload
+    std::mutex stage_down_mu;
+    void *stage_down[STAGE_N] = {nullptr, nullptr, nullptr};
+    hipEvent_t stage_down_ev[STAGE_N] = {nullptr, nullptr, nullptr};
 };
 
 extern "C" hipStream_t chroma_internal_stream(chroma_ctx *ctx) { return ctx->stream; }
@@ -3623,6 +3627,7 @@ int chroma_shutdown(chroma_ctx *ctx)
     chroma_comm_destroy(ctx);
     { std::lock_guard<std::mutex> lock(ctx->pool_mu); pool_release_all(ctx); for (hipEvent_t e : ctx->pool_events) hipEventDestroy(e); ctx->pool_events.clear(); }
     for (int i = 0; i < chroma_ctx::STAGE_N; i++) { if (ctx->stage[i]) hipHostFree(ctx->stage[i]); if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]); }
+    for (int i = 0; i < chroma_ctx::STAGE_N; i++) { if (ctx->stage_down[i]) hipHostFree(ctx->stage_down[i]); if (ctx->stage_down_ev[i]) hipEventDestroy(ctx->stage_down_ev[i]); }
     hipStreamDestroy(ctx->copy_stream);
     if (ctx->queue_a) hipFree(ctx->queue_a);
     if (ctx->queue_b) hipFree(ctx->queue_b);
@@ -3836,26 +3841,26 @@ int chroma_upload(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes
 // threads copy the previous one out to (pageable, possibly never touched) destination memory in parallel
 static int staged_dtoh(chroma_ctx *ctx, hipStream_t stream, void *h_dst, const void *d_src, size_t nbytes)
 {
-    std::lock_guard<std::mutex> lock(ctx->stage_mu);
+    std::lock_guard<std::mutex> lock(ctx->stage_down_mu);
     for (int i = 0; i < chroma_ctx::STAGE_N; i++)
-        if (!ctx->stage[i]) {
-            HIP_TRY(hipHostMalloc(&ctx->stage[i], chroma_ctx::STAGE_BYTES, hipHostMallocDefault));
-            HIP_TRY(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+        if (!ctx->stage_down[i]) {
+            HIP_TRY(hipHostMalloc(&ctx->stage_down[i], chroma_ctx::STAGE_BYTES, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->stage_down_ev[i], hipEventDisableTiming));
         }
     const size_t npieces = (nbytes + chroma_ctx::STAGE_BYTES - 1) / chroma_ctx::STAGE_BYTES;
     auto issue = [&](size_t i) -> hipError_t {
         const size_t off = i * chroma_ctx::STAGE_BYTES, len = std::min(chroma_ctx::STAGE_BYTES, nbytes - off);
         const int k = (int)(i % chroma_ctx::STAGE_N);
-        hipError_t e = hipMemcpyAsync(ctx->stage[k], (const char *)d_src + off, len, hipMemcpyDeviceToHost, stream);
-        return e != hipSuccess ? e : hipEventRecord(ctx->stage_ev[k], stream);
+        hipError_t e = hipMemcpyAsync(ctx->stage_down[k], (const char *)d_src + off, len, hipMemcpyDeviceToHost, stream);
+        return e != hipSuccess ? e : hipEventRecord(ctx->stage_down_ev[k], stream);
     };
     HIP_TRY(issue(0));
     for (size_t i = 0; i < npieces; i++) {
         if (i + 1 < npieces) HIP_TRY(issue(i + 1));               // (its buffer was copied out two pieces ago)
         const size_t off = i * chroma_ctx::STAGE_BYTES, len = std::min(chroma_ctx::STAGE_BYTES, nbytes - off);
         const int k = (int)(i % chroma_ctx::STAGE_N);
-        HIP_TRY(hipEventSynchronize(ctx->stage_ev[k]));
-        const char *src = (const char *)ctx->stage[k];
+        HIP_TRY(hipEventSynchronize(ctx->stage_down_ev[k]));
+        const char *src = (const char *)ctx->stage_down[k];
         char *dst = (char *)h_dst + off;
         chroma_host::parallel_for(len, [&](size_t a, size_t b) { memcpy(dst + a, src + a, b - a); }, 1u << 20);
     }
