@@ -4004,9 +4004,26 @@ int chroma_geometry_create(chroma_ctx *ctx, const chroma_geometry_desc *d, chrom
         const char *where = getenv("CHROMA_WIDE_BUILD");
         if (topology == chroma_host::WIDE_TOPOLOGY_LEVELS && !(where && !strcmp(where, "host"))) {
             void *h = nullptr;
-            if ((rc = chroma_wide_build_device(ctx, d->nodes, d->nnodes, d->ntriangles, &h, nullptr, nullptr, nullptr)) != CHROMA_OK) { chroma_geometry_destroy(g); return rc; }
-            wt = std::move(*(chroma_host::WideTree *)h);
-            delete (chroma_host::WideTree *)h;
+            rc = chroma_wide_build_device(ctx, d->nodes, d->nnodes, d->ntriangles, &h, nullptr, nullptr, nullptr);
+            if (rc == (int)hipErrorOutOfMemory) {
+                // (the builder's scratch -- ~150 bytes per triangle -- did not fit beside what the caller keeps on the card:
+                //  give the pool's parked blocks back and try once more; then the host cores build the SAME tree)
+                (void)hipGetLastError();
+                chroma_pool_trim(ctx);
+                rc = chroma_wide_build_device(ctx, d->nodes, d->nnodes, d->ntriangles, &h, nullptr, nullptr, nullptr);
+            }
+            if (rc == (int)hipErrorOutOfMemory) {
+                (void)hipGetLastError();
+                fprintf(stderr, "chroma_geometry_create: no room on the device for the tree builder's scratch: building the same tree on the host cores\n");
+                if (chroma_host::build_wide_tree(d->nodes, d->nnodes, d->ntriangles, wt, werr, topology) != 0) {
+                    chroma_geometry_destroy(g);
+                    return set_error(CHROMA_ERR_INVALID, "%s", werr.c_str());
+                }
+            } else if (rc != CHROMA_OK) { chroma_geometry_destroy(g); return rc; }
+            else {
+                wt = std::move(*(chroma_host::WideTree *)h);
+                delete (chroma_host::WideTree *)h;
+            }
         } else if (chroma_host::build_wide_tree(d->nodes, d->nnodes, d->ntriangles, wt, werr, topology) != 0) {
             chroma_geometry_destroy(g);
             return set_error(CHROMA_ERR_INVALID, "%s", werr.c_str());

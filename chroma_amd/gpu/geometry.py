@@ -57,7 +57,16 @@ class PackedGeometry(object):
                 from chroma_amd.gpu import tools as gtools
                 default = os.environ.get('CHROMA_TREE', 'levels') == 'levels' and os.environ.get('CHROMA_WIDE_BUILD') != 'host'
                 ctx = gtools._current if default else None
-            wide = _lib.wide_build(self.arrays['nodes'], self.desc.ntriangles, ctx=ctx)
+            try:
+                wide = _lib.wide_build(self.arrays['nodes'], self.desc.ntriangles, ctx=ctx)
+            except _lib.ChromaError as exc:
+                if ctx is None or 'out of memory' not in str(exc).lower():
+                    raise
+                # (the builder's scratch, ~150 bytes per triangle, did not fit beside what is on the card: the host cores
+                #  build the same tree, bit for bit)
+                logger.warning('no room on the device for the tree builder: building the wide tree on the host cores')
+                ctx.pool_trim()
+                wide = _lib.wide_build(self.arrays['nodes'], self.desc.ntriangles)
         self.put('wide_nodes', wide['wnodes'], np.uint32)
         self.put('wide_tri_to_record', wide['tri_to_record'], np.uint32)
         self.put('wide_record_to_tri', wide['record_to_tri'], np.uint32)

@@ -269,3 +269,30 @@ def test_least_area_collapse_beats_the_greedy_one():
         assert _node_area_sum(dp['wnodes']) < _node_area_sum(greedy['wnodes'])
         for w in (dp, greedy):
             assert _lib.wide_validate(w, nt)
+
+
+def test_levels_topology_does_not_depend_on_the_thread_count():
+    """The default topology leaves nothing to the schedule: one thread, three threads and all of them give the same wide
+    tree, record maps and ranks (the round-2 topology, 'sah', made its top part from sets whose size followed the thread
+    count) -- which is what lets the device builder reproduce it bit for bit (tests/test_gpu_wide.py)."""
+    g = create_geometry_from_obj(demo.tiny())
+    nodes = np.ascontiguousarray(g.bvh.nodes)
+    nt = len(g.mesh.triangles)
+    old = os.environ.get('CHROMA_HOST_THREADS')
+    trees = []
+    try:
+        for threads in ('1', '3', None):
+            if threads is None:
+                os.environ.pop('CHROMA_HOST_THREADS', None)
+            else:
+                os.environ['CHROMA_HOST_THREADS'] = threads
+            trees.append(_wide(nodes, nt, 'levels'))
+    finally:
+        if old is None:
+            os.environ.pop('CHROMA_HOST_THREADS', None)
+        else:
+            os.environ['CHROMA_HOST_THREADS'] = old
+    for other in trees[1:]:
+        for key in ('wnodes', 'tri_to_record', 'record_to_tri', 'rank'):
+            assert np.array_equal(trees[0][key], other[key]), key
+    assert _lib.wide_validate(trees[0], nt)
