@@ -7,7 +7,8 @@
 //
 //   top-down, per level of the binary tree (segments = the sets of that level, in triangle-array order):
 //     k_classify         a set of one triangle becomes a leaf; the others go to one of three lists by size
-//     k_split_small      2..32 triangles: ONE WAVE per set -- ranks by counting (readlane), boxes moved to sorted order with
+//     k_split_tiny       2..8 triangles: ONE THREAD per set (registers, a sorting network)
+//     k_split_small      9..32 triangles: ONE WAVE per set -- ranks by counting (readlane), boxes moved to sorted order with
 //                        ds_permute, prefix / suffix unions by lane scans, the cost in doubles, the first minimum by a wave
 //                        reduction, the set written back sorted on the winning axis
 //     k_split_wave       33..2048: one wave per set -- centroid bounds, 3 x 32 bins filled with LDS atomics, the same scans
@@ -87,6 +88,7 @@ struct Lap {
 constexpr uint32_t LEAFBIT = 0x80000000u;       // binary node: w = LEAFBIT | position of the triangle; else w = left child (right = w + 1)
 constexpr int NBINS = 32;                        // SAH_BINS of wide_build.cpp
 constexpr uint32_t SWEEP_MAX = 32;               // SWEEP_MAX of wide_build.cpp
+constexpr uint32_t TINY_MAX = 8;                 // sets up to this size are swept by ONE THREAD each (k_split_tiny)
 constexpr uint32_t WAVE_MAX = 2048;              // sets up to this size are split by one wave
 constexpr uint32_t CHUNK = 4096;                 // triangles per block of the large-set kernels
 constexpr int BIN_WORDS = 7;                     // lo[3], hi[3], count
@@ -234,7 +236,7 @@ __global__ void k_ref_unpack(const unsigned long long *rank_leaf, uint32_t ntria
 
 // ---- a level, top-down ---------------------------------------------------------------------------------------------------
 __global__ void k_classify(const uint4 *segs, uint32_t nseg, const uint4 *in, uint4 *bin, uint32_t *dev_to_tri, uint32_t *flag,
-                           uint32_t *list_small, uint32_t *list_wave, uint32_t *list_large, uint32_t *counters)
+                           uint32_t *list_small, uint32_t *list_wave, uint32_t *list_large, uint32_t *list_tiny, uint32_t *counters)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     int cls = -1;
@@ -247,20 +249,99 @@ __global__ void k_classify(const uint4 *segs, uint32_t nseg, const uint4 *in, ui
             flag[i] = 0u;
         } else {
             flag[i] = 1u;
-            cls = seg.y <= SWEEP_MAX ? 0 : seg.y <= WAVE_MAX ? 1 : 2;
+            cls = seg.y <= TINY_MAX ? 3 : seg.y <= SWEEP_MAX ? 0 : seg.y <= WAVE_MAX ? 1 : 2;
         }
     }
     const unsigned lane = threadIdx.x & 63u;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
+    for (int c = 0; c < 4; c++) {
         const unsigned long long m = __ballot(cls == c);
         if (!m) continue;
         uint32_t base = 0;
         const int leader = __ffsll((long long)m) - 1;
-        if ((int)lane == leader) base = atomicAdd(counters + c, (uint32_t)__popcll(m));
+        if ((int)lane == leader) base = atomicAdd(counters + (c == 3 ? 5 : c), (uint32_t)__popcll(m));
         base = __shfl(base, leader);
-        if (cls == c) (c == 0 ? list_small : c == 1 ? list_wave : list_large)[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+        if (cls == c) (c == 0 ? list_small : c == 1 ? list_wave : c == 2 ? list_large : list_tiny)[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
     }
+}
+
+// 2..TINY_MAX triangles: the same exact sweep, ONE THREAD per set.  Most sets of the lower levels are this small (half of all
+// inner nodes of a binary tree have two or three triangles below them), and a wave per set leaves 56 to 62 of its lanes idle:
+// k_split_small alone was half of the builder's time at C3.  Here the set lives in registers (every loop unrolled to eight
+// with guards): the keys, packed with the index, go through a 19-exchange sorting network -- which is the stable order --,
+// the triangles are picked in that order by select chains, prefix and suffix unions run sequentially.
+__device__ inline void cswap(uint32_t &a, uint32_t &b) { const uint32_t lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
+__global__ __launch_bounds__(256) void k_split_tiny(const uint32_t *list, uint32_t nlist, const uint4 *segs, const uint32_t *rank,
+                                                    const uint4 *in, uint4 *out, uint4 *bin, uint4 *next, uint32_t next_base)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nlist) return;
+    const uint32_t s = list[w];
+    const uint4 seg = segs[s];
+    const uint32_t first = seg.x, n = seg.y;
+    uint4 p[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = (uint32_t)i < n ? in[first + i] : make_uint4(0u, 0u, 0u, 0u);
+    double best = __builtin_huge_val();
+    uint32_t bidx = 0xFFFFFFFFu, orders[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        uint32_t k[8];          // doubled centroid << 3 | index: sorting these IS the stable sort by centroid
+#pragma unroll
+        for (int i = 0; i < 8; i++) k[i] = (uint32_t)i < n ? (cent2(axis_word(p[i], a)) << 3 | (uint32_t)i) : 0xFFFFFFFFu;
+        cswap(k[0], k[1]); cswap(k[2], k[3]); cswap(k[4], k[5]); cswap(k[6], k[7]);
+        cswap(k[0], k[2]); cswap(k[1], k[3]); cswap(k[4], k[6]); cswap(k[5], k[7]);
+        cswap(k[1], k[2]); cswap(k[5], k[6]); cswap(k[0], k[4]); cswap(k[3], k[7]);
+        cswap(k[1], k[5]); cswap(k[2], k[6]);
+        cswap(k[1], k[4]); cswap(k[3], k[6]);
+        cswap(k[2], k[4]); cswap(k[3], k[5]);
+        cswap(k[3], k[4]);
+        uint32_t order = 0;     // nibble r = index of the triangle of rank r
+        BoxC q[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t idx = k[r] & 7u;
+            order |= idx << (4 * r);
+            uint4 t = p[0];
+#pragma unroll
+            for (int i = 1; i < 8; i++) if (idx == (uint32_t)i) t = p[i];
+            q[r] = (uint32_t)r < n ? boxc_of(t) : boxc_identity();
+        }
+        orders[a] = order;
+        double la[8], ra[8];
+        BoxC run = boxc_identity();
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            for (int c = 0; c < 3; c++) { run.lo[c] = min(run.lo[c], q[r].lo[c]); run.hi[c] = max(run.hi[c], q[r].hi[c]); }
+            la[r] = boxc_area(run);
+        }
+        run = boxc_identity();
+#pragma unroll
+        for (int r = 7; r >= 1; r--) {
+            for (int c = 0; c < 3; c++) { run.lo[c] = min(run.lo[c], q[r].lo[c]); run.hi[c] = max(run.hi[c], q[r].hi[c]); }
+            ra[r] = boxc_area(run);
+        }
+#pragma unroll
+        for (int c = 0; c < 7; c++) {
+            if ((uint32_t)c + 1u < n) {
+                const double cost = la[c] * (double)(c + 1) + ra[c + 1] * (double)(n - (uint32_t)c - 1u);
+                if (cost < best) { best = cost; bidx = (uint32_t)a * 32u + (uint32_t)c; }
+            }
+        }
+    }
+    const uint32_t axis = bidx >> 5, nl = (bidx & 31u) + 1u;
+    const uint32_t order = axis == 0u ? orders[0] : axis == 1u ? orders[1] : orders[2];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if ((uint32_t)r < n) {
+            const uint32_t idx = (order >> (4 * r)) & 7u;
+            uint4 t = p[0];
+#pragma unroll
+            for (int i = 1; i < 8; i++) if (idx == (uint32_t)i) t = p[i];
+            out[first + r] = t;
+        }
+    }
+    make_children(seg, nl, rank[s], bin, next, next_base);
 }
 
 // 2..32 triangles: the exact sweep of split_sweep (wide_build.cpp), one wave per set
@@ -753,12 +834,12 @@ int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nn
     // ---- the binary tree, level by level
     const size_t nb = 2 * (size_t)np - 1;
     uint4 *d_bin, *d_segs_a, *d_segs_b, *d_lsplit;
-    uint32_t *d_dev_to_tri, *d_list[3], *d_nch, *d_ch0, *d_chunk_l, *d_chunk_nl, *d_chunk_off, *d_lcb, *d_lbins;
+    uint32_t *d_dev_to_tri, *d_list[4], *d_nch, *d_ch0, *d_chunk_l, *d_chunk_nl, *d_chunk_off, *d_lcb, *d_lbins;
     DEV_TRY(arena.get(&d_bin, nb));
     DEV_TRY(arena.get(&d_segs_a, np)); DEV_TRY(arena.get(&d_segs_b, np));
     DEV_TRY(arena.get(&d_flag, np)); DEV_TRY(arena.get(&d_rank, np));
     DEV_TRY(arena.get(&d_dev_to_tri, np));
-    for (int c = 0; c < 3; c++) DEV_TRY(arena.get(&d_list[c], c == 0 ? (size_t)np / 2 + 1 : c == 1 ? (size_t)np / (SWEEP_MAX + 1) + 1 : (size_t)np / (WAVE_MAX + 1) + 1));
+    for (int c = 0; c < 4; c++) DEV_TRY(arena.get(&d_list[c], c == 3 ? (size_t)np / 2 + 1 : c == 0 ? (size_t)np / (TINY_MAX + 1) + 1 : c == 1 ? (size_t)np / (SWEEP_MAX + 1) + 1 : (size_t)np / (WAVE_MAX + 1) + 1));
     const size_t max_large = (size_t)np / (WAVE_MAX + 1) + 1, max_chunks = (size_t)np / CHUNK + max_large + 1;
     DEV_TRY(arena.get(&d_nch, max_large)); DEV_TRY(arena.get(&d_ch0, max_large));
     DEV_TRY(arena.get(&d_lcb, max_large * 6)); DEV_TRY(arena.get(&d_lbins, max_large * BINS_WORDS)); DEV_TRY(arena.get(&d_lsplit, max_large));
@@ -775,17 +856,18 @@ int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nn
         if (level_base.size() > 4096) return chroma_internal_set_error(CHROMA_ERR_INTERNAL, "chroma_wide_build_device: the binary tree does not end");
         DEV_TRY(hipMemsetAsync(d_counters, 0, 8 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(k_classify, dim3(blocks_for(nseg)), dim3(256), 0, stream, d_segs_a, nseg, d_prims_a, d_bin, d_dev_to_tri, d_flag,
-                           d_list[0], d_list[1], d_list[2], d_counters);
+                           d_list[0], d_list[1], d_list[2], d_list[3], d_counters);
         { size_t b = tmp_bytes; DEV_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_flag, d_rank, (int)nseg, stream)); }
         hipLaunchKernelGGL(k_last_sum, dim3(1), dim3(64), 0, stream, d_rank, d_flag, nseg, d_counters + 3);
-        uint32_t h[4];
+        uint32_t h[6];                  // [0] small, [1] wave, [2] large, [3] sets to split, [4] chunks (below), [5] tiny
         DEV_TRY(hipMemcpyAsync(h, d_counters, sizeof h, hipMemcpyDeviceToHost, stream));
         DEV_TRY(hipStreamSynchronize(stream));
         level_base.push_back(base); level_count.push_back(nseg);
-        const uint32_t nsmall = h[0], nwave = h[1], nlarge = h[2], nonleaf = h[3];
-        if (nsmall + nwave + nlarge != nonleaf) return chroma_internal_set_error(CHROMA_ERR_INTERNAL, "chroma_wide_build_device: level %zu: lists of %u + %u + %u sets, %u to split", level_base.size() - 1, nsmall, nwave, nlarge, nonleaf);
+        const uint32_t nsmall = h[0], nwave = h[1], nlarge = h[2], nonleaf = h[3], ntiny = h[5];
+        if (ntiny + nsmall + nwave + nlarge != nonleaf) return chroma_internal_set_error(CHROMA_ERR_INTERNAL, "chroma_wide_build_device: level %zu: lists of %u + %u + %u + %u sets, %u to split", level_base.size() - 1, ntiny, nsmall, nwave, nlarge, nonleaf);
         if (nonleaf == 0) break;
         const uint32_t next_base = base + nseg;
+        if (ntiny) hipLaunchKernelGGL(k_split_tiny, dim3(blocks_for(ntiny)), dim3(256), 0, stream, d_list[3], ntiny, d_segs_a, d_rank, d_prims_a, d_prims_b, d_bin, d_segs_b, next_base);
         if (nsmall) hipLaunchKernelGGL(k_split_small, dim3(blocks_for(nsmall, 4)), dim3(256), 0, stream, d_list[0], nsmall, d_segs_a, d_rank, d_prims_a, d_prims_b, d_bin, d_segs_b, next_base);
         if (nwave) hipLaunchKernelGGL(k_split_wave, dim3(blocks_for(nwave, 4)), dim3(256), 0, stream, d_list[1], nwave, d_segs_a, d_rank, d_prims_a, d_prims_b, d_bin, d_segs_b, next_base);
         if (nlarge) {
@@ -816,7 +898,7 @@ int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nn
     { const int rc_ = chroma_internal_dtoh(ctx, t->dev_to_tri.data(), d_dev_to_tri, (size_t)np * 4u); if (rc_ != CHROMA_OK) return rc_; }
     arena.release(d_prims_a); arena.release(d_prims_b); arena.release(d_segs_a); arena.release(d_segs_b); arena.release(d_flag); arena.release(d_rank);
     arena.release(d_dev_to_tri);
-    for (int c = 0; c < 3; c++) arena.release(d_list[c]);
+    for (int c = 0; c < 4; c++) arena.release(d_list[c]);
     arena.release(d_nch); arena.release(d_ch0); arena.release(d_lcb); arena.release(d_lbins); arena.release(d_lsplit);
     arena.release(d_chunk_l); arena.release(d_chunk_nl); arena.release(d_chunk_off);
     if (lap.on) fprintf(stderr, "[wide device] %zu levels of the binary tree\n", level_base.size());

@@ -18,6 +18,9 @@ done
 fi
 if [[ $part != *2* ]]; then rm -rf /dev/shm/chroma_geo_cache; cat $out/bench_*.json; exit 0; fi
 export CHROMA_BENCH_NO_EXACT=1      # (the profiles are of the default walk: no extra batch through the literal one)
+# (the profiles are of the propagate path: the geometry comes from the cache -- filled here if PART=2 runs on a box of its own --
+#  so that the builders' kernels, run once per geometry, do not head the per-kernel list)
+[ -d /dev/shm/chroma_geo_cache ] || python bench.py --no-cpu-baseline --steps 1 --warmup 0 > /dev/null 2> $out/cache_fill.log
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_c3 -- python3 bench.py --no-cpu-baseline > $out/rocprof_c3.json 2> $out/rocprof_c3.log || exit 1
 python tools/prof_summary.py $out/rocprof_c3 $out/rocprof_c3_default_summary.txt bench.py
@@ -38,5 +41,9 @@ tools/pmc_physics.sh $out/pmc_physics_raw > $out/pmc_physics.txt 2>&1
 rm -rf $out/pmc_physics_raw
 CHROMA_BENCH_NO_EXACT= python bench.py --no-cpu-baseline > $out/bench_c3_with_traffic.json 2> $out/bench_c3_with_traffic.log
 tools/isa_report.sh > $out/isa_resources.txt 2>/dev/null
+# the geometry set-up on its own: phases (CHROMA_TIMING) and the builders' kernels
+CHROMA_TIMING=1 python tools/time_geometry_build.py c3 > $out/wide_device_build.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_geo -- python3 tools/time_geometry_build.py c3 > /dev/null 2> $out/rocprof_geo.log && python tools/prof_summary.py $out/rocprof_geo $out/rocprof_geometry_build_summary.txt tools/time_geometry_build.py
+rm -rf $out/rocprof_geo
 rm -rf /dev/shm/chroma_geo_cache
 cat $out/bench_*.json
