@@ -405,3 +405,37 @@ def test_c2_device_bvh_equals_the_host_builder(gpu, c2):
 
 def test_c3_device_bvh_equals_the_host_builder(gpu, c3):
     _device_bvh_equals_host(c3, 'C3 29k PMTs')
+
+
+# ---- the derived wide tree at full size: the device builder against its host twin --------------------------------------
+def _device_wide_tree_equals_host_twin(gpu, cfg, what):
+    """chroma_wide_build_device (csrc/wide_device.hip) == CHROMA_TREE=levels on the host cores (csrc/wide_build.cpp):
+    wide nodes, both record maps and the reference test ranks, bit for bit."""
+    import time
+    from chroma_amd import _lib
+    nodes, nt = cfg.packed.arrays['nodes'], cfg.packed.desc.ntriangles
+    t0 = time.time()
+    dev = _lib.wide_build(nodes, nt, ctx=gpu.get_context())
+    t1 = time.time()
+    old = os.environ.get('CHROMA_TREE')
+    os.environ['CHROMA_TREE'] = 'levels'
+    try:
+        host = _lib.wide_build(nodes, nt)
+    finally:
+        if old is None:
+            del os.environ['CHROMA_TREE']
+        else:
+            os.environ['CHROMA_TREE'] = old
+    t2 = time.time()
+    print('%s: %d wide nodes; device builder %.1f s, host twin %.1f s' % (what, len(dev['wnodes']), t1 - t0, t2 - t1))
+    assert dev['depth'] == host['depth']
+    for key in ('wnodes', 'tri_to_record', 'record_to_tri', 'rank'):
+        assert np.array_equal(dev[key], host[key]), (what, key)
+
+
+def test_c2_device_wide_tree_equals_its_host_twin(gpu, c2):
+    _device_wide_tree_equals_host_twin(gpu, c2, 'C2 demo.detector()')
+
+
+def test_c3_device_wide_tree_equals_its_host_twin(gpu, c3):
+    _device_wide_tree_equals_host_twin(gpu, c3, 'C3 29k PMTs')
