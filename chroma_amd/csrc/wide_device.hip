@@ -525,30 +525,58 @@ __global__ __launch_bounds__(256) void k_large_bounds(const uint32_t *chunk_l, c
 __global__ __launch_bounds__(256) void k_large_bins(const uint32_t *chunk_l, const uint32_t *ch0, const uint32_t *list, const uint4 *segs,
                                                     const uint4 *in, const uint32_t *lcb, uint32_t *lbins)
 {
-    __shared__ uint32_t b[BINS_WORDS];
+    // (one set of bins PER WAVE: near the top of the tree the triangles of a chunk fall into a few bins, and 256 threads
+    //  queueing on the same LDS words was most of this kernel's time)
+    __shared__ uint32_t s_b[4][BINS_WORDS];
     const ChunkView v = chunk_view(blockIdx.x, chunk_l, ch0, list, segs);
     uint32_t cmin[3], ext[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) { cmin[a] = lcb[(size_t)v.l * 6u + a]; ext[a] = lcb[(size_t)v.l * 6u + 3 + a] - cmin[a]; }
-    for (uint32_t i = threadIdx.x; i < (uint32_t)BINS_WORDS; i += 256u) b[i] = (i % BIN_WORDS) < 3u ? 0xFFFFFFFFu : 0u;
+    for (uint32_t i = threadIdx.x; i < 4u * (uint32_t)BINS_WORDS; i += 256u) (&s_b[0][0])[i] = ((i % BINS_WORDS) % BIN_WORDS) < 3u ? 0xFFFFFFFFu : 0u;
     __syncthreads();
-    for (uint32_t i = v.begin + threadIdx.x; i < v.end; i += 256u) {
-        const uint4 p = in[v.seg.x + i];
+    uint32_t *b = s_b[threadIdx.x >> 6];
+    const unsigned lane = threadIdx.x & 63u;
+    for (uint32_t base = v.begin; base < v.end; base += 256u) {          // (every lane goes round: the wave reductions below need them all)
+        const uint32_t i = base + threadIdx.x;
+        const bool ok = i < v.end;
+        const uint4 p = ok ? in[v.seg.x + i] : make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0u);      // (lo 0xFFFF, hi 0: the identity)
+        const unsigned long long m = __ballot(ok);
+        if (m == 0ull) continue;                        // (a wave past the end of the chunk)
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             if (!ext[a]) continue;
-            uint32_t *e = b + ((uint32_t)a * NBINS + bin_of(cent2(axis_word(p, a)), cmin[a], ext[a])) * BIN_WORDS;
-            atomicMin(e + 0, p.x & 0xFFFFu); atomicMin(e + 1, p.y & 0xFFFFu); atomicMin(e + 2, p.z & 0xFFFFu);
-            atomicMax(e + 3, p.x >> 16); atomicMax(e + 4, p.y >> 16); atomicMax(e + 5, p.z >> 16);
-            atomicAdd(e + 6, 1u);
+            const uint32_t k = ok ? bin_of(cent2(axis_word(p, a)), cmin[a], ext[a]) : 0xFFFFFFFFu;
+            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);        // (lane 0 of a round always holds a triangle)
+            uint32_t *e = b + ((uint32_t)a * NBINS + (ok ? k : 0u)) * BIN_WORDS;
+            if (__ballot(ok && k != k0) == 0ull) {
+                // the whole wave in ONE bin (the usual case a few levels down, where a chunk is a small region): reduce in
+                // registers, one lane touches the bin
+                const uint32_t lx = wave_min_u32(p.x & 0xFFFFu), ly = wave_min_u32(p.y & 0xFFFFu), lz = wave_min_u32(p.z & 0xFFFFu);
+                const uint32_t hx = wave_max_u32(p.x >> 16), hy = wave_max_u32(p.y >> 16), hz = wave_max_u32(p.z >> 16);
+                if (lane == 0) {
+                    atomicMin(e + 0, lx); atomicMin(e + 1, ly); atomicMin(e + 2, lz);
+                    atomicMax(e + 3, hx); atomicMax(e + 4, hy); atomicMax(e + 5, hz);
+                    atomicAdd(e + 6, (uint32_t)__popcll(m));
+                }
+            } else if (ok) {
+                atomicMin(e + 0, p.x & 0xFFFFu); atomicMin(e + 1, p.y & 0xFFFFu); atomicMin(e + 2, p.z & 0xFFFFu);
+                atomicMax(e + 3, p.x >> 16); atomicMax(e + 4, p.y >> 16); atomicMax(e + 5, p.z >> 16);
+                atomicAdd(e + 6, 1u);
+            }
         }
     }
     __syncthreads();
     uint32_t *g = lbins + (size_t)v.l * BINS_WORDS;
     for (uint32_t i = threadIdx.x; i < (uint32_t)BINS_WORDS; i += 256u) {
         const uint32_t kind = i % BIN_WORDS;
-        if (b[i - kind + 6u] == 0u) continue;           // an empty bin of this chunk
-        if (kind < 3u) atomicMin(g + i, b[i]); else if (kind < 6u) atomicMax(g + i, b[i]); else atomicAdd(g + i, b[i]);
+        uint32_t count = 0, val = kind < 3u ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            count += s_b[w][i - kind + 6u];
+            val = kind < 3u ? min(val, s_b[w][i]) : kind < 6u ? max(val, s_b[w][i]) : val + s_b[w][i];
+        }
+        if (count == 0u) continue;                      // an empty bin of this chunk
+        if (kind < 3u) atomicMin(g + i, val); else if (kind < 6u) atomicMax(g + i, val); else atomicAdd(g + i, val);
     }
 }
 __global__ __launch_bounds__(256) void k_large_decide(const uint32_t *list, uint32_t nlarge, const uint4 *segs, const uint32_t *rank,
