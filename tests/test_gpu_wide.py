@@ -140,3 +140,24 @@ def test_stack_need_by_passes_on_the_device_is_the_backward_sweep(ctx):
             need[i] = max(best, rank)
         gg = gpu.GPUGeometry(g)
         assert gg.stack_need() == max(1, int(need[0])), build.__name__
+
+
+def test_device_tree_on_random_soups_around_the_kernels_size_limits(ctx):
+    """Triangle soups whose sizes sit on the borders between the builder's kernels (one thread per set up to 8 triangles, one
+    wave up to 32 and up to 2048, chunks of 4096 beyond), with duplicated and degenerate triangles mixed in."""
+    from chroma_amd import _lib
+    from chroma_amd.geometry import Geometry, Solid, Mesh, vacuum
+    from chroma_amd.loader import create_geometry_from_obj
+    for seed, n in enumerate((2, 3, 8, 9, 32, 33, 64, 2048, 2049, 4096, 4097, 8193, 30000)):
+        rng = np.random.default_rng(100 + seed)
+        centre = rng.uniform(-50, 50, size=(n, 1, 3)).astype(np.float32)
+        tri = centre + rng.normal(0, 6, size=(n, 3, 3)).astype(np.float32)
+        if n >= 64:
+            tri[n // 2:n // 2 + n // 8] = tri[n // 2]                 # a block of identical triangles
+            tri[-n // 16:, :, 0] = 1.0                                  # slivers in a plane
+        g = Geometry()
+        g.add_solid(Solid(Mesh(tri.reshape(-1, 3), np.arange(3 * n, dtype=np.int32).reshape(-1, 3), remove_null_triangles=False), vacuum, vacuum))
+        g = create_geometry_from_obj(g)
+        nodes = np.ascontiguousarray(g.bvh.nodes)
+        nt = len(g.mesh.triangles)
+        _same(_lib.wide_build(nodes, nt, ctx=ctx), _host_levels(nodes, nt), '%d triangles' % n)
