@@ -1036,6 +1036,9 @@ __device__ inline uint32_t quad_or_u32(uint32_t v)
     return v;
 }
 
+#ifndef QUAD_OVERFLOW_RESET
+#define QUAD_OVERFLOW_RESET 0
+#endif
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD_WAVES_PER_EU, QUAD_WAVES_PER_EU))) void
 k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
@@ -1233,10 +1236,20 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                             if (pos < QUAD_STACK) { stack_n[pos] = eb.w; stack_t[pos] = tb; }
                             else if (pos < QUAD_STACK + COOP_SPILL) { spill[pos - QUAD_STACK] = make_uint2(eb.w, __float_as_uint(tb)); if (COUNT) atomicAdd(&counters->stack_spills, 1ull); }
                         }
+#if QUAD_OVERFLOW_RESET
                         if (sp > QUAD_STACK + COOP_SPILL) {          // cannot happen: the host checked the tree's need
                             triangle_index = HIT_RETRY;
                             active = false; npend = 0; cur = WIDE_NONE; sp = 0;
                         }
+#else
+                        // A stack deeper than LDS part + spill area cannot happen: chroma_geometry_create works the tree's need out
+                        // and the launch code only picks this walk when it fits.  Rounds 1-3 nevertheless reset the ray's whole
+                        // state here -- a merge of five loop-carried values with an arm that never runs, which cost the arm that
+                        // always runs eight register copies per node visit.  The guards above already keep every write inside
+                        // the two areas; clamping the depth keeps every later read inside them too, and the overflow is counted
+                        // (stats.stack_overflows, which the tests hold at zero).
+                        if (sp > QUAD_STACK + COOP_SPILL) { atomicAdd(&counters->stack_overflows, 1ull); sp = QUAD_STACK + COOP_SPILL; }
+#endif
                     }
                 }
             }
