@@ -1039,6 +1039,9 @@ __device__ inline uint32_t quad_or_u32(uint32_t v)
 #ifndef QUAD_OVERFLOW_RESET
 #define QUAD_OVERFLOW_RESET 0
 #endif
+#ifndef QUAD_POP_TWO_ARMS
+#define QUAD_POP_TWO_ARMS 0
+#endif
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD_WAVES_PER_EU, QUAD_WAVES_PER_EU))) void
 k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
@@ -1156,6 +1159,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
             TQ_STAMP(tq_a); tq_iters++; tq_active += (unsigned)__popcll(__ballot(active && j == 0));
 #endif
             __builtin_amdgcn_s_setprio(3);       // a wave about to fetch its next node goes before waves that compute
+#if QUAD_POP_TWO_ARMS
             if (!__any(sp > QUAD_STACK)) {
                 // (node, distance) read together, the entry kept or dropped by a select: no branch inside the loop
                 while (active && cur == WIDE_NONE) {
@@ -1176,6 +1180,26 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                 }
                 if (cur == WIDE_NONE) active = false;
             }
+#else
+            // a ray whose stack reaches into the global spill area (a few in 1e8) first pops from there -- a prefix that
+            // changes its state in place -- and every ray then runs the ONE pop loop over the LDS part: no second arm whose
+            // state has to be merged with the first at every node visit
+            if (__any(sp > QUAD_STACK)) {
+                while (active && cur == WIDE_NONE && sp > QUAD_STACK) {
+                    sp--;
+                    const uint2 se = spill[sp - QUAD_STACK];
+                    cur = (__uint_as_float(se.y) > prune_t) ? WIDE_NONE : se.x;
+                }
+            }
+            // (node, distance) read together, the entry kept or dropped by a select: no branch inside the loop
+            while (active && cur == WIDE_NONE) {
+                if (sp == 0) { active = false; break; }
+                sp--;
+                const uint32_t n = stack_n[sp];
+                const float t = stack_t[sp];
+                cur = (t > prune_t) ? WIDE_NONE : n;
+            }
+#endif
 #if QUAD_TIMING
             TQ_STAMP(tq_b); tq_pop += tq_b - tq_a;
 #endif
