@@ -2126,6 +2126,9 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
 #ifndef PHYS_ENDED_AOS
 #define PHYS_ENDED_AOS 0     // experiment (profiles/r03/ab_physics_ended_aos.txt): a photon that ends in k_physics goes as ONE 64-byte
 #endif                       // record to final[photon id] and a streaming kernel fills the caller's ten arrays at the end of the call
+#ifndef PHYS_STAGE_LDS
+#define PHYS_STAGE_LDS 0     // experiment: survivors' records through LDS as in k_load_working -- no gain here (profiles/r03/ab_lds_staged_stores.txt)
+#endif
 template <bool FULL>
 __global__ __launch_bounds__(PHYS_BLOCK_OF(FULL)) __attribute__((amdgpu_waves_per_eu(FULL ? PHYS_WAVES_PER_EU : PHYS_PLAIN_WAVES_PER_EU))) void
 k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32_t *output_queue, float4 *work_out,
@@ -2141,6 +2144,9 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
     // ends here is written to the caller's arrays (the only time they are touched).
     constexpr int BLOCK = PHYS_BLOCK_OF(FULL);
     __shared__ uint32_t s_counts[BLOCK / WAVE + 1];
+    // (survivor records leave through LDS in the plain build: see the end of the round; the all-models build has no registers to spare)
+    constexpr bool STAGE = (PHYS_STAGE_LDS != 0) && !FULL;
+    __shared__ float4 s_stage[STAGE ? BLOCK / WAVE : 1][STAGE ? WAVE * 4 : 1];
     // The 512 slots of a round are dealt to the threads BY THE SURFACE THEY HIT (the material code of the winning
     // triangle's record): what a photon does at a black wall, at PMT glass, at the photocathode, at a mirror, a thin
     // film or a wavelength shifter are different, long branches, and a wave that holds all kinds executes them all.
@@ -2275,6 +2281,32 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
         }
     }
     const uint32_t at = block_queue_append<BLOCK / WAVE>(output_queue, alive, photon_id, s_counts);
+    if constexpr (STAGE) {
+        // the survivors of a wave take consecutive slots: their 64-byte records (and then their ray records) leave through
+        // LDS as whole kilobytes instead of as 64 partial lines per store instruction (see k_load_working)
+        const unsigned long long tm = __ballot(alive);
+        const uint32_t nsurv = (uint32_t)__popcll(tm), rnk = (uint32_t)__popcll(tm & ((1ull << lane_id()) - 1ull));
+        const uint32_t first_slot = nsurv ? (uint32_t)__shfl(at, __ffsll((long long)tm) - 1) - 1u : 0u;
+        float4 *stg = s_stage[threadIdx.x / WAVE];
+        if (alive) {
+            float4 *w = stg + 4 * rnk;
+            w[0] = make_float4(p.position.x, p.position.y, p.position.z, p.wavelength);
+            w[1] = make_float4(p.direction.x, p.direction.y, p.direction.z, p.time);
+            w[2] = make_float4(p.polarization.x, p.polarization.y, p.polarization.z, p.weight);
+            w[3] = make_float4(__uint_as_float(p.history), __uint_as_float(counter), __int_as_float(last_hit_record), __uint_as_float(photon_id));
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t q = lane_id(); q < 4u * nsurv; q += WAVE) work_out[4 * (size_t)first_slot + q] = stg[q];
+        __builtin_amdgcn_wave_barrier();
+        if (rays_next) {
+            // the survivor's ray for the next step (see k_ray_setup): the next launch re-normalises unless the reference's
+            // last launch has begun -- which k_step_begin of THIS step has already decided
+            if (alive) make_ray_record(g, stg + 4 * rnk, p.position, p.direction, renorm_next, last_hit_record);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t q = lane_id(); q < 4u * nsurv; q += WAVE) rays_next[4 * (size_t)first_slot + q] = stg[q];
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else
     if (alive) {
         float4 *w = work_out + 4 * (size_t)(at - 1u);
         w[0] = make_float4(p.position.x, p.position.y, p.position.z, p.wavelength);
@@ -2493,6 +2525,9 @@ k_physics_deal(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, u
 // k_load_working also is the initial queue of GPUPhotons.propagate (chroma/gpu/photon.py:206-216: the
 // ncopies clones of a photon next to each other); photons that are already terminal are left out -- and
 // thereby untouched (propagate.cu:258).
+#ifndef LOAD_STAGE_LDS
+#define LOAD_STAGE_LDS 1
+#endif
 __global__ __launch_bounds__(PHYS_BLOCK) void
 k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t n, uint32_t ncopies, uint32_t true_n, float4 *rays,
                uint32_t *coherence, const uint32_t *order = nullptr)
@@ -2502,6 +2537,9 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
     // (`coherence`: [0] += waves whose photons share an origin and lie within a cone of 50 mrad, [1] += waves looked at:
     //  what decides between k_raycast_packet and k_raycast_quad for the first step.  A heuristic: it steers speed only.)
     __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
+#if LOAD_STAGE_LDS
+    __shared__ float4 s_stage[PHYS_BLOCK / WAVE][WAVE * 4];
+#endif
     uint32_t coh_yes = 0, coh_all = 0;
     for (uint64_t block_base = (uint64_t)blockIdx.x * PHYS_BLOCK; block_base < n; block_base += (uint64_t)gridDim.x * PHYS_BLOCK) {
         uint64_t j = block_base + threadIdx.x;
@@ -2513,6 +2551,39 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
             take = (flags & CHROMA_TERMINAL_MASK) == 0;
         }
         const uint32_t at = block_queue_append<PHYS_BLOCK / WAVE>(queue, take, photon_id, s_counts);
+#if LOAD_STAGE_LDS
+        // The survivors of a wave land in consecutive slots (block_queue_append), 64 bytes each -- but a lane's four
+        // 16-byte stores are 64 bytes apart from its neighbours': 64 partial lines per store instruction.  The records go
+        // through LDS instead and leave as whole kilobytes: store i of the wave writes bytes [1024 i, 1024 (i + 1)) of
+        // the wave's span.
+        const unsigned long long tm = __ballot(take);
+        const uint32_t nsurv = (uint32_t)__popcll(tm), rnk = (uint32_t)__popcll(tm & ((1ull << lane_id()) - 1ull));
+        const uint32_t first_slot = nsurv ? (uint32_t)__shfl(at, __ffsll((long long)tm) - 1) - 1u : 0u;
+        float4 *st = s_stage[threadIdx.x / WAVE];
+        v3 pos = mk3(0.f, 0.f, 0.f), dir = mk3(0.f, 0.f, 1.f);
+        int lh = -1;
+        if (take) {
+            pos = load3(pv.pos, photon_id); dir = load3(pv.dir, photon_id);
+            const v3 pol = load3(pv.pol, photon_id);
+            lh = pv.last_hit_triangles[photon_id];
+            lh = (lh >= 0 && (uint32_t)lh < g.ntriangles) ? (int)g.tri_to_dev[lh] : -1;
+            float4 *w = st + 4 * rnk;
+            w[0] = make_float4(pos.x, pos.y, pos.z, pv.wavelengths[photon_id]);
+            w[1] = make_float4(dir.x, dir.y, dir.z, pv.t[photon_id]);
+            w[2] = make_float4(pol.x, pol.y, pol.z, pv.weights[photon_id]);
+            w[3] = make_float4(__uint_as_float(flags), __uint_as_float(pv.rng_counters[photon_id]), __int_as_float(lh), __uint_as_float(photon_id));
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t q = lane_id(); q < 4u * nsurv; q += WAVE) work[4 * (size_t)first_slot + q] = st[q];
+        __builtin_amdgcn_wave_barrier();
+        if (rays) {
+            if (take) make_ray_record(g, st + 4 * rnk, pos, dir, 1, lh);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t q = lane_id(); q < 4u * nsurv; q += WAVE) rays[4 * (size_t)first_slot + q] = st[q];
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (take) {
+#else
         if (take) {
             v3 pos = load3(pv.pos, photon_id), dir = load3(pv.dir, photon_id), pol = load3(pv.pol, photon_id);
             int lh = pv.last_hit_triangles[photon_id];
@@ -2523,6 +2594,7 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
             w[2] = make_float4(pol.x, pol.y, pol.z, pv.weights[photon_id]);
             w[3] = make_float4(__uint_as_float(flags), __uint_as_float(pv.rng_counters[photon_id]), __int_as_float(lh), __uint_as_float(photon_id));
             if (rays) make_ray_record(g, rays + 4 * (size_t)(at - 1u), pos, dir, 1, lh);
+#endif
             if (coherence) {
                 // against the wave's first taken lane (the lanes of a wave land in consecutive slots)
                 const unsigned long long m = __ballot(true);
