@@ -6,7 +6,7 @@
 // subtree; here every step is a pass over an array, one LEVEL of the tree at a time:
 //
 //   top-down, per level of the binary tree (segments = the sets of that level, in triangle-array order):
-//     k_classify         a set of one triangle becomes a leaf; the others go to one of three lists by size
+//     k_classify         a set of one triangle becomes a leaf; the others go to one of four lists by size
 //     k_split_tiny       2..8 triangles: ONE THREAD per set (registers, a sorting network)
 //     k_split_small      9..32 triangles: ONE WAVE per set -- ranks by counting (readlane), boxes moved to sorted order with
 //                        ds_permute, prefix / suffix unions by lane scans, the cost in doubles, the first minimum by a wave
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_split_tiny(const uint32_t *list, uint32
     make_children(seg, nl, rank[s], bin, next, next_base);
 }
 
-// 2..32 triangles: the exact sweep of split_sweep (wide_build.cpp), one wave per set
+// 9..32 triangles (and any set up to 32 the tiny kernel does not take): the exact sweep of split_sweep (wide_build.cpp), one wave per set
 __global__ __launch_bounds__(256) void k_split_small(const uint32_t *list, uint32_t nlist, const uint4 *segs, const uint32_t *rank,
                                                      const uint4 *in, uint4 *out, uint4 *bin, uint4 *next, uint32_t next_base)
 {
