@@ -297,7 +297,9 @@ __global__ void k_step_begin(const uint32_t *in_queue, uint32_t *out_queue, Step
 // other slots (NaN, 1/d not moderate) get their hit entry -- and their place in the retry list -- right
 // here.  The photon comes from the dense working set (see k_load_working).
 // the record of one ray at `r`; returns its status (0 = cast, HIT_NAN, HIT_RETRY)
-__device__ inline int make_ray_record(const GeoView &g, float4 *r, v3 origin, v3 direction, int renorm, int last_hit)
+// `literal`: the record of the exact walk (k_raycast_literal) carries the reference's own two per-ray constants, 1/d and
+// -o/d (mesh.h:52-53), in place of the fused slab constants a and b.
+__device__ inline int make_ray_record(const GeoView &g, float4 *r, v3 origin, v3 direction, int renorm, int last_hit, bool literal = false)
 {
     int status;
     v3 a = mk3(0.f, 0.f, 0.f), b = mk3(0.f, 0.f, 0.f);
@@ -311,6 +313,10 @@ __device__ inline int make_ray_record(const GeoView &g, float4 *r, v3 origin, v3
                         cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
         if (!moderate) {
             status = HIT_RETRY;
+        } else if (literal) {
+            a = inv_dir;
+            b = noid;
+            status = 0;
         } else {
             a = ray_fast(g, noid, inv_dir, 1.0f).a;
             // b exactly as ray_fast forms it (blo = b - G a, bhi = b + G a are rebuilt by the kernels; G travels in r[2].w)
@@ -332,14 +338,14 @@ __device__ inline int make_ray_record(const GeoView &g, float4 *r, v3 origin, v3
 // settles the few slots whose status is not 0 when it meets them (`settle`).  The cross-check walks keep it.
 __global__ __launch_bounds__(256) void
 k_ray_setup(GeoView g, const float4 *work, const StepState *st, float4 *rays,
-            int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint32_t *retry_counter)
+            int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint32_t *retry_counter, int literal = 0)
 {
     const int nthreads = (int)st->n, renorm = (int)st->renorm;
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < nthreads; slot += gridDim.x * blockDim.x) {
         const float4 *w = work + 4 * (size_t)slot;
         const float4 w0 = w[0], w1 = w[1], w3 = w[3];
         const int status = make_ray_record(g, rays + 4 * (size_t)slot, mk3(w0.x, w0.y, w0.z), mk3(w1.x, w1.y, w1.z), renorm,
-                                           __float_as_int(w3.z));
+                                           __float_as_int(w3.z), literal != 0);
         if (status != 0) {
             hit_triangle[slot] = status;
             hit_distance[slot] = 0.0f;
@@ -2106,6 +2112,8 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
     if (lane_id() == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
 }
 
+#include "raycast_literal.h"
+
 #ifndef PHYS_BLOCK
 #define PHYS_BLOCK 512
 #endif
@@ -3270,24 +3278,47 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     if (need > STACK_LDS + STACK_SCRATCH)
         return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
     const bool have_wide = geom->view.wnodes != nullptr;
-    if (ctx->wide_walk == CHROMA_WALK_LITERAL) {
+    if (ctx->wide_walk == CHROMA_WALK_LITERAL || ctx->wide_walk == CHROMA_WALK_LITERAL_LANE) {
         // the reference's own loop for every ray (mesh.h:42-118 as it stands: its tree, its order, its box arithmetic,
-        // every triangle tested the moment its leaf box is entered), then the physics on the results as they are
+        // every triangle tested the moment its leaf box is entered), then the physics on the results as they are.
+        // LITERAL: k_raycast_literal (four lanes per ray, persistent waves; raycast_literal.h) + the strict lane-per-ray
+        // loop for the few rays whose 1/d is not moderate; LITERAL_LANE: the strict loop for every ray (the cross-check).
+        const bool lane_walk = ctx->wide_walk == CHROMA_WALK_LITERAL_LANE;
         StepState *st = ctx->d_step;
         hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st,
                            use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8), first_n);
         if (ev) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+        if (!lane_walk && !ctx->coop_spill) {
+            HIP_TRY(hipSetDevice(ctx->device));
+            HIP_TRY(ctx_malloc(ctx, (void **)&ctx->coop_spill, spill_entries(ctx) * sizeof(uint2)));
+        }
         unsigned sblocks = (unsigned)std::min<long long>((n_upper + 255) / 256, (long long)ctx->physics_blocks * 4);
         hipLaunchKernelGGL(k_ray_setup, dim3(sblocks), dim3(256), 0, ctx->stream, geom->view, work_in, st, ctx->rays,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, &st->retry);
+                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, &st->retry, lane_walk ? 0 : 1);
         if (ev) { HIP_TRY(hipEventRecord(ev[3], ctx->stream)); HIP_TRY(hipEventRecord(ev[5], ctx->stream)); }
-        const unsigned lblocks = (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK, (long long)ctx->persistent_waves);
-        if (ctx->counting)
-            hipLaunchKernelGGL((k_raycast_retry<true, true>), dim3(lblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
-                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
-        else
-            hipLaunchKernelGGL((k_raycast_retry<false, true>), dim3(lblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
-                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
+        if (lane_walk) {
+            const unsigned lblocks = (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK, (long long)ctx->persistent_waves);
+            if (ctx->counting)
+                hipLaunchKernelGGL((k_raycast_retry<true, true>), dim3(lblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
+                                   ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
+            else
+                hipLaunchKernelGGL((k_raycast_retry<false, true>), dim3(lblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
+                                   ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
+        } else {
+            const unsigned lwaves = (unsigned)std::min<long long>((n_upper + 15) / 16, (long long)ctx->quad_waves);
+            const unsigned rblocks = (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK, 8 * 256);
+            if (ctx->counting) {
+                hipLaunchKernelGGL((k_raycast_literal<true>), dim3(lwaves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
+                                   ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk);
+                hipLaunchKernelGGL((k_raycast_retry<true>), dim3(rblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
+                                   ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
+            } else {
+                hipLaunchKernelGGL((k_raycast_literal<false>), dim3(lwaves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
+                                   ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk);
+                hipLaunchKernelGGL((k_raycast_retry<false>), dim3(rblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
+                                   ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
+            }
+        }
         if (ev) HIP_TRY(hipEventRecord(ev[1], ctx->stream));
         const bool deal = PHYS_DEAL != 0 && geom->view.plain_optics != 0;
         const int pb = deal ? PHYS_DEAL_BLOCK : PHYS_BLOCK_OF(geom->view.plain_optics == 0);
@@ -3709,7 +3740,8 @@ int chroma_init(int device, chroma_ctx **out)
         if (const char *e = getenv("CHROMA_WALK"))
             ctx->wide_walk = !strcmp(e, "reference") ? CHROMA_WALK_REFERENCE : !strcmp(e, "wide") ? CHROMA_WALK_WIDE
                            : !strcmp(e, "coop") ? CHROMA_WALK_COOP : !strcmp(e, "pair") ? CHROMA_WALK_PAIR
-                           : (!strcmp(e, "literal") || !strcmp(e, "exact")) ? CHROMA_WALK_LITERAL : CHROMA_WALK_QUAD;
+                           : (!strcmp(e, "literal") || !strcmp(e, "exact")) ? CHROMA_WALK_LITERAL
+                           : !strcmp(e, "literal_lane") ? CHROMA_WALK_LITERAL_LANE : CHROMA_WALK_QUAD;
         if (const char *e = getenv("CHROMA_PACKET")) ctx->packet_mode = !strcmp(e, "on") ? 1 : !strcmp(e, "auto") ? 2 : 0;
         if (const char *e = getenv("CHROMA_AUTOSORT")) ctx->autosort_mode = !strcmp(e, "on") || !strcmp(e, "1") ? 1 : !strcmp(e, "off") || !strcmp(e, "0") ? 0 : 2;
         if (const char *e = getenv("CHROMA_RAY_CHUNK")) ctx->ray_chunk = std::max(64, atoi(e));
@@ -4460,7 +4492,7 @@ int chroma_intersect_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthrea
     if (need > STACK_LDS + STACK_SCRATCH)
         return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
     if (geom->view.wnodes && geom->wide_stack_need <= COOP_STACK + COOP_SPILL && ctx->wide_walk != CHROMA_WALK_REFERENCE &&
-        ctx->wide_walk != CHROMA_WALK_LITERAL)
+        ctx->wide_walk != CHROMA_WALK_LITERAL && ctx->wide_walk != CHROMA_WALK_LITERAL_LANE)
         return distance_to_mesh_fast(ctx, geom, nthreads, d_origin, d_direction, d_last_hit, d_distance, d_triangle);
     dim3 grid((unsigned)((nthreads + PROP_BLOCK - 1) / PROP_BLOCK)), block(PROP_BLOCK);
 #define LAUNCH(N, C) hipLaunchKernelGGL((k_distance_to_mesh<N, C>), grid, block, 0, ctx->stream, geom->view, nthreads, \
@@ -4571,7 +4603,7 @@ int chroma_set_walk(chroma_ctx *ctx, int32_t mode)
 {
     if (!ctx) return set_error(CHROMA_ERR_INVALID, "null ctx");
     if (mode != CHROMA_WALK_REFERENCE && mode != CHROMA_WALK_WIDE && mode != CHROMA_WALK_COOP && mode != CHROMA_WALK_QUAD &&
-        mode != CHROMA_WALK_PAIR && mode != CHROMA_WALK_LITERAL)
+        mode != CHROMA_WALK_PAIR && mode != CHROMA_WALK_LITERAL && mode != CHROMA_WALK_LITERAL_LANE)
         return set_error(CHROMA_ERR_INVALID, "unknown walk mode %d", mode);
     ctx->wide_walk = mode;
     return CHROMA_OK;

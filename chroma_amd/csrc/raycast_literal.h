@@ -1,0 +1,267 @@
+// raycast_literal.h -- the exact walk: chroma/cuda/mesh.h:42-118 for every ray, four lanes per ray.
+//
+// (Included by chroma_hip.hip; needs its StepState, HIT_* codes and the quad DPP helpers.)
+//
+// What "literal" means.  The reference's intersect_mesh is a depth-first walk over child RANGES: pop a range,
+// test its children IN ORDER against the ray -- intersect_box in the reference's float arithmetic on boxes
+// dequantised as world_origin + q * world_scale (geometry.h:31-47, intersect.h:107-147), pruned by the best hit
+// SO FAR (mesh.h:16-34) -- a leaf that passes has its triangle tested AT ONCE (mesh.h:82-101), an inner node that
+// passes is pushed; the range pushed last is walked next.  The answer depends on that order whenever a
+// Moeller-Trumbore result is numerically erratic, so an exact walk has to keep it.
+//
+// How it runs here.  A wavefront carries 16 rays; the 4 lanes of a quad take FOUR CONSECUTIVE CHILDREN of the
+// range their ray is scanning: one 16-byte node each, 64 contiguous bytes per quad.
+//   * The four box tests are independent of each other and run in parallel: the slab arithmetic is the
+//     reference's own, operation for operation (two multiply-add pairs per bound, not fused; the two faces of an
+//     axis as one packed operation).
+//   * What the reference does with the results is sequential -- a triangle hit in child k changes the pruning
+//     distance for children k+1.. -- and is replayed in order from the four (box distance, hit distance) pairs:
+//     a handful of DPP broadcasts.  A chunk without a triangle to test (most: inner ranges) cannot change the
+//     pruning distance, so its passing children are pushed at once at prefix-count positions.
+//   * Triangle tests are the divergent part: a quad that has one to do WAITS (its lanes sit out the node
+//     iterations) until LIT_TRI_MIN quads are waiting or nothing else can run, then all waiting quads test
+//     their up-to-four triangles in one pass and replay.  Nothing is postponed past anything it could
+//     influence: a ray never looks at another node before its triangle has been tested.
+//   * Triangles are tested speculatively within a chunk (child k+1's triangle before child k's result is
+//     known); the replay discards a test the reference would not have made.  Discarded tests change nothing.
+//   * Persistent waves with refill, an LDS stack of LIT_STACK words per ray (a stack entry is the packed `w`
+//     word of a node, as in the reference's two arrays) with the rest in the per-ray slice of the global spill
+//     area the other walks use.
+// Rays whose 1/d is not "moderate" (|1/d| >= 1e30 or not finite: one per ~3e7 bomb photons) do not come here:
+// k_ray_setup lists them for k_raycast_retry (intersect_mesh_strict, whose intersect_box handles them).
+#pragma once
+
+#ifndef LIT_STACK
+#define LIT_STACK 32          // stack words per ray in LDS
+#endif
+#define LIT_STRIDE (LIT_STACK + 1)       // odd: staggers the banks
+#ifndef LIT_TRI_MIN
+#define LIT_TRI_MIN 5         // run the triangle pass once this many of the 16 quads wait for it
+#endif
+#ifndef LIT_REFILL_MIN
+#define LIT_REFILL_MIN 4      // refill once this many of the 16 rays are done
+#endif
+#ifndef LIT_WAVES_PER_EU
+#define LIT_WAVES_PER_EU 8
+#endif
+#define LIT_SPILL (2 * COOP_SPILL)       // words of a ray's slice of the global spill area (uint2 entries there)
+
+// lane k of the quad's value in every lane of the quad (quad_perm [k,k,k,k])
+template <int K>
+__device__ inline uint32_t quad_bcast_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xF, 0xF, false);
+}
+template <int K>
+__device__ inline float quad_bcast_f32(float v) { return __uint_as_float(quad_bcast_u32<K>(__float_as_uint(v))); }
+
+// intersect_box (intersect.h:107-147) on a packed node (geometry.h:31-47), for a ray whose 1/d is finite on every
+// axis: bit for bit box_tmin() of propagate_device.h.  lower/upper = wo + q * ws, t = bound * (1/d) + (-o/d); every
+// multiplication and addition rounded on its own (-ffp-contract=off), the two faces of an axis side by side.
+__device__ inline float box_tmin_exact(uint4 nd, float ws, float wox, float woy, float woz, v3 inv_dir, v3 noid)
+{
+    const f32x2 qx = {(float)(nd.x & 0xFFFFu), (float)(nd.x >> 16)};
+    const f32x2 qy = {(float)(nd.y & 0xFFFFu), (float)(nd.y >> 16)};
+    const f32x2 qz = {(float)(nd.z & 0xFFFFu), (float)(nd.z >> 16)};
+    const f32x2 s = {ws, ws};
+    const f32x2 bx = (f32x2){wox, wox} + qx * s, by = (f32x2){woy, woy} + qy * s, bz = (f32x2){woz, woz} + qz * s;
+    const f32x2 tx = bx * (f32x2){inv_dir.x, inv_dir.x} + (f32x2){noid.x, noid.x};
+    const f32x2 ty = by * (f32x2){inv_dir.y, inv_dir.y} + (f32x2){noid.y, noid.y};
+    const f32x2 tz = bz * (f32x2){inv_dir.z, inv_dir.z} + (f32x2){noid.z, noid.z};
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)),
+                                       __builtin_fmaxf(__builtin_fminf(tz.x, tz.y), 0.0f));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)),
+                                       __builtin_fmaxf(tz.x, tz.y));
+    return (tmin > tmax) ? -1.0f : tmin;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(LIT_WAVES_PER_EU, LIT_WAVES_PER_EU))) void
+k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_triangle, float *hit_distance,
+                  uint2 *spill_base, DeviceCounters *counters, int big_chunk)
+{
+    const int nthreads = (int)st->n;
+    if ((long long)blockIdx.x * 16 >= nthreads) return;
+    uint32_t *work_counter = &st->work;
+    const int chunk = ((long long)nthreads > 4ll * big_chunk * (long long)gridDim.x) ? big_chunk : 16;
+    static_assert(PROP_BLOCK == WAVE, "one wave per workgroup");
+    __shared__ uint32_t s_lds[16 * LIT_STRIDE];
+    const unsigned lane = lane_id();
+    const unsigned j = lane & 3u, gshift = lane & ~3u, grp = lane >> 2;
+    const uint32_t jbit = 1u << j, below = jbit - 1u;
+    uint32_t *stack = s_lds + grp * LIT_STRIDE;
+    uint32_t *spill = (uint32_t *)(spill_base + ((size_t)blockIdx.x * 16 + grp) * COOP_SPILL);
+    const float ws = g.world_scale, wox = g.world_origin[0], woy = g.world_origin[1], woz = g.world_origin[2];
+    LaneCounters cnt = {0, 0, 0, 0};
+
+    // per-ray state, identical in the 4 lanes of a quad
+    bool has_ray = false, active = false, waiting = false;
+    int slot = 0;
+    v3 origin = mk3(0.f, 0.f, 0.f), direction = mk3(0.f, 0.f, 1.f), inv_dir = mk3(0.f, 0.f, 1.f), noid = mk3(0.f, 0.f, 0.f);
+    int last_hit = -1, triangle_index = -1;
+    float min_distance = -1.0f;
+    uint32_t cur = 0, end = 0;           // the children of the range being scanned that are still to do: [cur, end)
+    int sp = 0;
+    // what a waiting quad holds of its chunk: this lane's node word and box distance, the quad's decision word
+    uint32_t w_node = 0, w_qm = 0;
+    float w_tmin = 0.f;
+    uint32_t loc_next = 0, loc_end = 0;
+    bool exhausted = false;
+
+    for (;;) {
+        // ---- refill idle quads
+        const unsigned long long idle_mask = __ballot(!has_ray && j == 0);
+        const int n_idle = __popcll(idle_mask);
+        bool more = !exhausted || loc_next < loc_end;
+        if (more && (n_idle >= LIT_REFILL_MIN || n_idle == 16)) {
+            if (loc_next >= loc_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work_counter, (uint32_t)chunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + (uint32_t)chunk >= (uint32_t)nthreads) exhausted = true;
+                loc_next = min(base, (uint32_t)nthreads);
+                loc_end = min(base + (uint32_t)chunk, (uint32_t)nthreads);
+            }
+            const uint32_t idx = loc_next + (uint32_t)__popcll(idle_mask & ((1ull << gshift) - 1ull));
+            loc_next = min(loc_end, loc_next + (uint32_t)n_idle);
+            if (!has_ray && idx < loc_end) {
+                slot = (int)idx;
+                const float4 *r = rays + 4 * (size_t)slot;
+                const float4 r0 = r[0], r1 = r[1];
+                if (__float_as_int(r1.w) == 0) {                 // (the other slots were settled by k_ray_setup)
+                    const float4 r2 = r[2], r3 = r[3];           // 1/d and -o/d (k_ray_setup, literal records)
+                    origin = mk3(r0.x, r0.y, r0.z);
+                    direction = mk3(r1.x, r1.y, r1.z);
+                    inv_dir = mk3(r2.x, r2.y, r2.z);
+                    noid = mk3(r3.x, r3.y, r3.z);
+                    last_hit = __float_as_int(r0.w);
+                    triangle_index = -1;
+                    min_distance = -1.0f;
+                    sp = 0;
+                    // the root is tested like any other node (mesh.h:55): a one-node range
+                    cur = 0; end = 1;
+                    has_ray = true;
+                    active = true;
+                    waiting = false;
+                }
+            }
+        }
+        if (!__any(has_ray)) {
+            if (exhausted && loc_next >= loc_end) break;
+            continue;
+        }
+
+        // ---- node phase: every quad that is not waiting for its triangles scans four children of its range
+        more = !exhausted || loc_next < loc_end;
+        const int stop_at = more ? max(0, (int)__popcll(__ballot(active && !waiting) & 0x1111111111111111ull) - (int)LIT_REFILL_MIN) : 0;
+        do {
+            __builtin_amdgcn_s_setprio(3);
+            const bool run = active && !waiting;
+            if (run && cur >= end) {
+                // the range is done: the one pushed last is next (mesh.h:68-72)
+                if (sp == 0) {
+                    active = false;
+                } else {
+                    sp--;
+                    const uint32_t w = (sp < LIT_STACK) ? stack[sp] : spill[sp - LIT_STACK];
+                    cur = w & ~CHROMA_NCHILD_MASK;
+                    end = cur + (w >> CHROMA_CHILD_BITS);
+                }
+            }
+            if (active && !waiting) {
+                const uint32_t idx = cur + j;
+                const bool valid = idx < end;
+                const uint4 nd = g.nodes[valid ? idx : end - 1u];
+                __builtin_amdgcn_s_setprio(0);
+                if (COUNT && j == 0 && end != 1u) cnt.nodes += min(4u, end - cur);      // (children only: mesh.h counts inside its loop, the root is tested before it)
+                cur += 4u;
+                const float tmin = box_tmin_exact(nd, ws, wox, woy, woz, inv_dir, noid);
+                // intersect_node (mesh.h:16-34) against the best hit known when the chunk is entered: a superset of what
+                // the replay lets through, the pruning distance only ever shrinks
+                const bool pass = valid && node_passes(tmin, min_distance);
+                const bool leaf = (nd.w >> CHROMA_CHILD_BITS) == 0u;
+                const bool is_tri = pass && leaf && (int)(nd.w & ~CHROMA_NCHILD_MASK) != last_hit;      // mesh.h:82
+                const bool is_inner = pass && !leaf;
+                const uint32_t qm = quad_or_u32((is_inner ? (jbit << 4) : 0u) | (is_tri ? jbit : 0u));
+                if ((qm & 0xFu) == 0u) {
+                    // no triangle in this chunk: nothing can change the pruning distance, the inner children that
+                    // pass go on the stack in order
+                    const uint32_t mi = qm >> 4;
+                    const int pos = sp + (int)__popc(mi & below);
+                    if (is_inner) {
+                        if (pos < LIT_STACK) stack[pos] = nd.w;
+                        else if (pos < LIT_STACK + LIT_SPILL) { spill[pos - LIT_STACK] = nd.w; if (COUNT) cnt.spills++; }
+                    }
+                    sp += (int)__popc(mi);
+                    // (cannot happen: chroma_geometry_create works the tree's need out and the launch code checks it)
+                    if (sp > LIT_STACK + LIT_SPILL) { if (j == 0) cnt.overflows++; sp = LIT_STACK + LIT_SPILL; }
+                } else {
+                    waiting = true;
+                    w_node = nd.w;
+                    w_tmin = tmin;
+                    w_qm = qm;
+                }
+            }
+        } while ((int)__popcll(__ballot(waiting) & 0x1111111111111111ull) < LIT_TRI_MIN &&
+                 (int)__popcll(__ballot(active && !waiting) & 0x1111111111111111ull) > stop_at);
+        __builtin_amdgcn_s_setprio(0);
+
+        // ---- triangle pass: every waiting quad tests the triangles of its chunk (one per lane), then replays the
+        // reference's loop over the four children in order
+        if (__any(waiting)) {
+            bool hit = false;
+            float distance = 0.0f;
+            if (waiting && (w_qm & jbit)) {
+                const float4 *tp = g.tri + TRI_STRIDE * (size_t)(w_node & ~CHROMA_NCHILD_MASK);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
+            }
+            const uint32_t hm = quad_or_u32(hit ? jbit : 0u);
+#define LIT_REPLAY(K)                                                                                                  \
+            {                                                                                                          \
+                const float tk = quad_bcast_f32<K>(w_tmin);                                                           \
+                const float dk = quad_bcast_f32<K>(distance);                                                         \
+                const uint32_t wk = quad_bcast_u32<K>(w_node);                                                        \
+                if (waiting && (w_qm & (0x11u << K)) && node_passes(tk, min_distance)) {                              \
+                    if (w_qm & (1u << K)) {                                                                            \
+                        if (COUNT && j == 0) cnt.tris++;                                                               \
+                        if ((hm & (1u << K)) && (triangle_index == -1 || dk < min_distance)) {       /* mesh.h:88 */    \
+                            triangle_index = (int)(wk & ~CHROMA_NCHILD_MASK);                                          \
+                            min_distance = dk;                                                                         \
+                        }                                                                                              \
+                    } else {                                                                                           \
+                        if (j == 0) {                                                                                  \
+                            if (sp < LIT_STACK) stack[sp] = wk;                                                        \
+                            else if (sp < LIT_STACK + LIT_SPILL) { spill[sp - LIT_STACK] = wk; if (COUNT) cnt.spills++; } \
+                        }                                                                                              \
+                        if (sp < LIT_STACK + LIT_SPILL) sp++; else if (j == 0) cnt.overflows++;                        \
+                    }                                                                                                  \
+                }                                                                                                      \
+            }
+            LIT_REPLAY(0) LIT_REPLAY(1) LIT_REPLAY(2) LIT_REPLAY(3)
+#undef LIT_REPLAY
+            waiting = false;
+            __builtin_amdgcn_wave_barrier();      // (scheduling fence: lane 0 of a quad wrote stack words its other lanes will read)
+        }
+
+        // ---- retire finished rays
+        if (has_ray && !active) {
+            if (j == 0) {
+                hit_triangle[slot] = triangle_index;                 // record index or -1
+                hit_distance[slot] = min_distance;
+            }
+            has_ray = false;
+        }
+    }
+
+    const unsigned long long ov = wave_sum_u64(cnt.overflows);
+    if (COUNT) {
+        const unsigned long long nd = wave_sum_u64(cnt.nodes), tr = wave_sum_u64(cnt.tris), sx = wave_sum_u64(cnt.spills);
+        if (lane == 0) {
+            atomicAdd(&counters->nodes_visited, nd);
+            atomicAdd(&counters->triangles_tested, tr);
+            if (sx) atomicAdd(&counters->stack_spills, sx);
+        }
+    }
+    if (lane == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
+}

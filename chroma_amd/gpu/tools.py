@@ -86,7 +86,7 @@ class Context(object):
     def set_counting(self, enabled):
         _lib.check(self._lib.chroma_set_counting(self.handle, 1 if enabled else 0))
 
-    WALKS = {'reference': 0, 'wide': 1, 'coop': 2, 'quad': 3, 'pair': 4, 'literal': 5}
+    WALKS = {'reference': 0, 'wide': 1, 'coop': 2, 'quad': 3, 'pair': 4, 'literal': 5, 'literal_lane': 6}
 
     def set_walk(self, mode):
         """How the per-step ray cast walks.  'quad' (default), 'pair', 'coop', 'wide': the fast walks over the derived

@@ -465,7 +465,8 @@ int chroma_set_counting(chroma_ctx *ctx, int32_t enabled);
 #define CHROMA_WALK_COOP      2
 #define CHROMA_WALK_QUAD      3   /* the wide tree with four lanes per ray, two child entries per lane */
 #define CHROMA_WALK_PAIR      4   /* the wide tree with two lanes per ray, four child entries per lane  */
-#define CHROMA_WALK_LITERAL   5   /* chroma/cuda/mesh.h:42-118 literally, for every ray: exact, slow */
+#define CHROMA_WALK_LITERAL   5   /* chroma/cuda/mesh.h:42-118 literally, for every ray: exact (k_raycast_literal: four lanes per ray) */
+#define CHROMA_WALK_LITERAL_LANE 6 /* the same loop with one lane per ray and no refill (intersect_mesh_strict): LITERAL's cross-check */
 int chroma_set_walk(chroma_ctx *ctx, int32_t mode);
 
 /* The first step of a chroma_propagate call can go to k_raycast_packet: 64 rays per wavefront walk the wide tree as ONE
