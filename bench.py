@@ -343,6 +343,8 @@ def main():
     log('counting pass %.1f s: %.3f steps/photon, %.1f nodes/step, %.2f triangle tests/step -> %.0f B/step, %.0f B/photon; '
         'hit fraction %.4f; %d stack entries spilled' % (time.time() - t0, steps_pp, nodes_ps, tris_ps, bytes_per_step, bytes_per_photon,
                                                          count_n_stats['hits'] / nphotons, count_n_stats.get('stack_spills', 0)))
+    if count_n_stats.get('packet_nodes_visited'):
+        log('  diagnostic counters: %r' % {k: v for k, v in count_n_stats.items() if k.startswith('packet_')})
     if world > 1:
         assert count_n_stats['channel_sum'] >= count_n_stats['hits'], 'reduced channel counts smaller than this rank\'s own'
     else:

@@ -36,7 +36,7 @@
 #endif
 #define LIT_STRIDE (LIT_STACK + 1)       // odd: staggers the banks
 #ifndef LIT_TRI_MIN
-#define LIT_TRI_MIN 5         // run the triangle pass once this many of the 16 quads wait for it
+#define LIT_TRI_MIN 8         // run the triangle pass once this many of the 16 quads wait for it
 #endif
 #ifndef LIT_REFILL_MIN
 #define LIT_REFILL_MIN 4      // refill once this many of the 16 rays are done
@@ -44,6 +44,9 @@
 #ifndef LIT_WAVES_PER_EU
 #define LIT_WAVES_PER_EU 8
 #endif
+#ifndef LIT_DIAG
+#define LIT_DIAG 0            // diagnostic build: the counting kernel also reports wave iterations, quads running in them, triangle passes
+#endif                        // (through the packet_* fields of the statistics, which the literal walk does not otherwise use)
 #define LIT_SPILL (2 * COOP_SPILL)       // words of a ray's slice of the global spill area (uint2 entries there)
 
 // lane k of the quad's value in every lane of the quad (quad_perm [k,k,k,k])
@@ -107,6 +110,9 @@ k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tri
     float w_tmin = 0.f;
     uint32_t loc_next = 0, loc_end = 0;
     bool exhausted = false;
+#if LIT_DIAG
+    unsigned diag_iters = 0, diag_running = 0, diag_passes = 0, diag_waiting = 0;
+#endif
 
     for (;;) {
         // ---- refill idle quads
@@ -155,15 +161,27 @@ k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tri
         more = !exhausted || loc_next < loc_end;
         const int stop_at = more ? max(0, (int)__popcll(__ballot(active && !waiting) & 0x1111111111111111ull) - (int)LIT_REFILL_MIN) : 0;
         do {
+#if LIT_DIAG
+            if (COUNT) { diag_iters++; diag_running += (unsigned)__popcll(__ballot(active && !waiting) & 0x1111111111111111ull); }
+#endif
             __builtin_amdgcn_s_setprio(3);
-            const bool run = active && !waiting;
-            if (run && cur >= end) {
-                // the range is done: the one pushed last is next (mesh.h:68-72)
+            // the range is done: the one pushed last is next (mesh.h:68-72).  (A stack that reaches into the global spill
+            // area -- rare -- pops from there in a branch of its own: one pointer for both would be a flat load.)
+            const bool pop = active && !waiting && cur >= end;
+            if (__any(pop && sp > LIT_STACK)) {
+                if (pop && sp > LIT_STACK) {
+                    sp--;
+                    const uint32_t w = spill[sp - LIT_STACK];
+                    cur = w & ~CHROMA_NCHILD_MASK;
+                    end = cur + (w >> CHROMA_CHILD_BITS);
+                }
+            } 
+            if (pop && cur >= end) {
                 if (sp == 0) {
                     active = false;
                 } else {
                     sp--;
-                    const uint32_t w = (sp < LIT_STACK) ? stack[sp] : spill[sp - LIT_STACK];
+                    const uint32_t w = stack[sp];
                     cur = w & ~CHROMA_NCHILD_MASK;
                     end = cur + (w >> CHROMA_CHILD_BITS);
                 }
@@ -209,6 +227,9 @@ k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tri
         // ---- triangle pass: every waiting quad tests the triangles of its chunk (one per lane), then replays the
         // reference's loop over the four children in order
         if (__any(waiting)) {
+#if LIT_DIAG
+            if (COUNT) { diag_passes++; diag_waiting += (unsigned)__popcll(__ballot(waiting) & 0x1111111111111111ull); }
+#endif
             bool hit = false;
             float distance = 0.0f;
             if (waiting && (w_qm & jbit)) {
@@ -217,29 +238,40 @@ k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tri
                 hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
             }
             const uint32_t hm = quad_or_u32(hit ? jbit : 0u);
-#define LIT_REPLAY(K)                                                                                                  \
-            {                                                                                                          \
-                const float tk = quad_bcast_f32<K>(w_tmin);                                                           \
-                const float dk = quad_bcast_f32<K>(distance);                                                         \
-                const uint32_t wk = quad_bcast_u32<K>(w_node);                                                        \
-                if (waiting && (w_qm & (0x11u << K)) && node_passes(tk, min_distance)) {                              \
+            // Replay of mesh.h:74-108 over the chunk's four children in order.  Every lane of the quad fetches the four box
+            // distances and the four hit distances once (DPP broadcasts) and runs the same short chain on its own registers:
+            // `m` is the pruning distance as the reference would hold it after each child (negative: nothing hit yet, which
+            // is also what triangle_index == -1 says, a hit distance being > 1e-6), `win` the child whose triangle became
+            // the best hit, `acc` the inner children that pass and are pushed.
+            if (waiting) {
+                const float t0 = quad_bcast_f32<0>(w_tmin), t1 = quad_bcast_f32<1>(w_tmin), t2 = quad_bcast_f32<2>(w_tmin), t3 = quad_bcast_f32<3>(w_tmin);
+                const float d0 = quad_bcast_f32<0>(distance), d1 = quad_bcast_f32<1>(distance), d2 = quad_bcast_f32<2>(distance), d3 = quad_bcast_f32<3>(distance);
+                float m = min_distance;
+                uint32_t win = 4u, acc = 0u, ntested = 0u;
+#define LIT_REPLAY(K, TK, DK)                                                                                          \
+                if ((w_qm & (0x11u << K)) && node_passes(TK, m)) {                                                     \
                     if (w_qm & (1u << K)) {                                                                            \
-                        if (COUNT && j == 0) cnt.tris++;                                                               \
-                        if ((hm & (1u << K)) && (triangle_index == -1 || dk < min_distance)) {       /* mesh.h:88 */    \
-                            triangle_index = (int)(wk & ~CHROMA_NCHILD_MASK);                                          \
-                            min_distance = dk;                                                                         \
-                        }                                                                                              \
+                        ntested++;                                                                                     \
+                        if ((hm & (1u << K)) && (m < 0.0f || DK < m)) { m = DK; win = K; }          /* mesh.h:88 */     \
                     } else {                                                                                           \
-                        if (j == 0) {                                                                                  \
-                            if (sp < LIT_STACK) stack[sp] = wk;                                                        \
-                            else if (sp < LIT_STACK + LIT_SPILL) { spill[sp - LIT_STACK] = wk; if (COUNT) cnt.spills++; } \
-                        }                                                                                              \
-                        if (sp < LIT_STACK + LIT_SPILL) sp++; else if (j == 0) cnt.overflows++;                        \
+                        acc |= 1u << K;                                                                                \
                     }                                                                                                  \
-                }                                                                                                      \
-            }
-            LIT_REPLAY(0) LIT_REPLAY(1) LIT_REPLAY(2) LIT_REPLAY(3)
+                }
+                LIT_REPLAY(0, t0, d0) LIT_REPLAY(1, t1, d1) LIT_REPLAY(2, t2, d2) LIT_REPLAY(3, t3, d3)
 #undef LIT_REPLAY
+                if (COUNT && j == 0) cnt.tris += ntested;
+                const uint32_t wchild = quad_max_u32(j == win ? (w_node & ~CHROMA_NCHILD_MASK) + 1u : 0u);
+                if (win != 4u) { triangle_index = (int)wchild - 1; min_distance = m; }
+                if (acc) {                       // (a chunk that holds triangles AND inner nodes: rare)
+                    const int pos = sp + (int)__popc(acc & below);
+                    if (acc & jbit) {
+                        if (pos < LIT_STACK) stack[pos] = w_node;
+                        else if (pos < LIT_STACK + LIT_SPILL) { spill[pos - LIT_STACK] = w_node; if (COUNT) cnt.spills++; }
+                    }
+                    sp += (int)__popc(acc);
+                    if (sp > LIT_STACK + LIT_SPILL) { if (j == 0) cnt.overflows++; sp = LIT_STACK + LIT_SPILL; }
+                }
+            }
             waiting = false;
             __builtin_amdgcn_wave_barrier();      // (scheduling fence: lane 0 of a quad wrote stack words its other lanes will read)
         }
@@ -264,4 +296,11 @@ k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tri
         }
     }
     if (lane == 0 && ov) atomicAdd(&counters->stack_overflows, ov);
+#if LIT_DIAG
+    if (COUNT && lane == 0) {
+        atomicAdd(&counters->packet_nodes, (unsigned long long)diag_iters);
+        atomicAdd(&counters->packet_rays, (unsigned long long)diag_running);
+        atomicAdd(&counters->packet_tris, ((unsigned long long)diag_waiting << 32) | diag_passes);
+    }
+#endif
 }
