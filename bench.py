@@ -38,7 +38,11 @@ CONFIGS = {
 }
 C4_PHOTONS_PER_GPU = 125_000_000      # configs[3]: 1e9 photons sharded over 8 GPUs
 ENGINE_SEED = 12345
-SORT_DIRECTIONS = os.environ.get('CHROMA_BENCH_SORT', '1') != '0'      # photons in tools.argsort_direction order, as chroma/benchmark.py:80-82
+# `value` is measured on photons in GENERATION order (the Morton pre-sort of directions is "reported
+# separately").  CHROMA_BENCH_SORT=1 puts the headline batches themselves in tools.argsort_direction order before the clock
+# starts, as chroma/benchmark.py:80-82 does (round 3's headline input); either way the other input is timed over the same
+# number of batches after the headline and reported beside it (config.presorted / config.generation_order).
+SORT_DIRECTIONS = os.environ.get('CHROMA_BENCH_SORT', '0') != '0'
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 RAYCAST_KERNEL = {'reference': 'k_raycast_persistent', 'wide': 'k_raycast_wide', 'coop': 'k_raycast_coop'}.get(os.environ.get('CHROMA_WALK', ''), 'k_raycast_quad')
 
@@ -251,7 +255,8 @@ def main():
     free, total = ctx.mem_get_info()
     work_bytes = nphotons * (2 * 4 + 2 * 4 + 4 + 64 + 2 * 64) + (1 << 30)        # queues, hit hand-off, ray records, working sets
     batch_bytes = nphotons * 64
-    resident = (nbatches + 1) * batch_bytes + work_bytes + int(0.12 * nphotons) * 72 < 0.92 * free
+    sort_scratch = nphotons * 28                               # chroma_photons_sort_direction: codes, indices, radix-sort double buffers, one gathered array
+    resident = (nbatches + 1) * batch_bytes + work_bytes + sort_scratch + int(0.12 * nphotons) * 72 < 0.92 * free
     nbuffers = nbatches if resident else 2
     log('HBM: %.1f GB free of %.1f; %d batches of %.1f GB %s' % (free / 1e9, total / 1e9, nbatches, batch_bytes / 1e9,
         'resident' if resident else 'do not fit: %d buffers refilled inside the timed region' % nbuffers))
@@ -263,15 +268,19 @@ def main():
             self.struct = _structure(self.ph)
             self.id_base = None
 
-        def fill(self, index):
+        def fill(self, index, sort=None):
             # global photon ids: batch-major, then rank, then index -> independent of world size
             self.id_base = (index * world + rank) * nphotons
             pos = (ctypes.c_float * 3)(0.0, 0.0, 0.0)
             _lib.check(lib.chroma_generate_bomb(ctx.handle, ctypes.byref(self.struct), nphotons, ENGINE_SEED, self.id_base, pos, wl_lo, wl_hi))
-            if SORT_DIRECTIONS:
-                # chroma/benchmark.py:80-82: the reference's propagate benchmark puts its photons in the order of
-                # tools.argsort_direction before it starts the clock; same here, on the device
-                _lib.check(lib.chroma_photons_sort_direction(ctx.handle, ctypes.byref(self.struct), nphotons))
+            if SORT_DIRECTIONS if sort is None else sort:
+                self.sort()
+            return self
+
+        def sort(self):
+            # chroma/benchmark.py:80-82: the reference's propagate benchmark puts its photons in the order of
+            # tools.argsort_direction before it starts the clock; same here, on the device
+            _lib.check(lib.chroma_photons_sort_direction(ctx.handle, ctypes.byref(self.struct), nphotons))
             return self
 
     # per-step outputs, allocated once: per-channel arrays and the flat-hit buffers (get_flat_hits' destination)
@@ -365,12 +374,14 @@ def main():
         log('  warmup %d: %.1f ms wall' % (i, 1e3 * (time.perf_counter() - t_step)))
     sync_all()
     stats = {}
+    step_walls = []
     t_start = time.perf_counter()
     for i in range(args.warmup, nbatches):
         t_step = time.perf_counter()
         k0 = stats.get('kernel_ms', 0.0)
         run_step(batch_for(i), True, stats)
-        log('  step %d: %.1f ms wall, %.1f ms in propagate kernels' % (i - args.warmup, 1e3 * (time.perf_counter() - t_step), stats['kernel_ms'] - k0))
+        step_walls.append(time.perf_counter() - t_step)
+        log('  step %d: %.1f ms wall, %.1f ms in propagate kernels' % (i - args.warmup, 1e3 * step_walls[-1], stats['kernel_ms'] - k0))
     sync_all()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -422,23 +433,72 @@ def main():
     except Exception:
         pass
 
-    # ---- the exact walk's rate (one extra UNTIMED-for-the-headline batch): the reference's own traversal loop for every
-    # ray (chroma_set_walk LITERAL, GPUPhotons.propagate(exact=True)) on the same batch, same step definition
-    exact_rate = None
-    # (single-GPU runs only: run_step holds the all-reduce of the per-channel arrays, a collective EVERY rank would have to enter)
-    if world == 1 and not os.environ.get('CHROMA_BENCH_NO_EXACT') and os.environ.get('CHROMA_WALK', 'quad') == 'quad':
-        ctx.set_walk('literal')
-        try:
-            b = batch_for(0) if not resident else buffers[0].fill(20_000)
+    def rate_stats(walls):
+        """mean and standard deviation of the per-batch rates, and of the per-batch times, over one leg's batches"""
+        r = [nphotons / w for w in walls]
+        return {'value': float(np.mean(r)), 'std': float(np.std(r)), 'batches': len(r),
+                'ms_per_batch': 1e3 * float(np.mean(walls)), 'ms_per_batch_std': 1e3 * float(np.std(walls))}
+
+    def timed_leg(prepare, nleg):
+        """`nleg` batches through run_step, each between two device synchronisations (the same step definition as the
+        headline); `prepare(i)` returns batch i with its input ready BEFORE the clock starts."""
+        walls = []
+        for i in range(nleg):
+            b = prepare(i)
             ctx.synchronize()
             t0 = time.perf_counter()
             run_step(b, False, {})
             ctx.synchronize()
-            exact_rate = nphotons / (time.perf_counter() - t0)
+            walls.append(time.perf_counter() - t0)
+        return walls
+
+    headline_order = rate_stats(step_walls)
+    # (the extra legs below run on one GPU only: run_step holds the all-reduce of the per-channel arrays, a collective EVERY
+    #  rank would have to enter)
+    extra_legs = world == 1 and not os.environ.get('CHROMA_BENCH_NO_EXACT') and os.environ.get('CHROMA_WALK', 'quad') == 'quad'
+    nleg = int(os.environ.get('CHROMA_BENCH_LEG_BATCHES', args.steps))
+
+    def leg_batch(i, index_base, sort):
+        # (resident: buffer i of the headline's own set, refilled for the leg; else the two-buffer ring)
+        return (buffers[i % len(buffers)]).fill(index_base + i, sort=sort)
+
+    # ---- the OTHER input order over the same number of batches: photons put in tools.argsort_direction order before the clock
+    # starts, as the reference's own propagate benchmark does (chroma/benchmark.py:80-82) -- or, with CHROMA_BENCH_SORT=1,
+    # generation order -- and what the ordering itself costs on the device (it is NOT inside any timed region)
+    other_order = sort_cost = None
+    if extra_legs:
+        walls = timed_leg(lambda i: leg_batch(i, 30_000, not SORT_DIRECTIONS), nleg)
+        other_order = rate_stats(walls)
+        log('%s: %.4g +- %.2g photons/s over %d batches (%.1f +- %.1f ms)' % (
+            'photons pre-sorted by direction' if not SORT_DIRECTIONS else 'photons in generation order', other_order['value'], other_order['std'],
+            nleg, other_order['ms_per_batch'], other_order['ms_per_batch_std']))
+        sorts = []
+        for i in range(min(nleg, 5)):
+            b = leg_batch(i, 40_000, False)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            b.sort()
+            ctx.synchronize()
+            sorts.append(time.perf_counter() - t0)
+        sort_cost = {'ms_per_batch': 1e3 * float(np.mean(sorts)), 'std': 1e3 * float(np.std(sorts)), 'batches': len(sorts),
+                     'what': 'chroma_photons_sort_direction on the device (Morton code of theta and phi, radix sort, gather of the ten arrays); outside every timed region'}
+        log('direction sort of one batch on the device: %.1f +- %.1f ms' % (sort_cost['ms_per_batch'], sort_cost['std']))
+    presorted, generation = (headline_order, other_order) if SORT_DIRECTIONS else (other_order, headline_order)
+
+    # ---- the exact walk (chroma_set_walk LITERAL, GPUPhotons.propagate(exact=True)): chroma/cuda/mesh.h:42-118 for every ray,
+    # same step definition, same number of batches as the headline, photons in the headline's order
+    exact_walk = None
+    if extra_legs:
+        ctx.set_walk('literal')
+        try:
+            walls = timed_leg(lambda i: leg_batch(i, 20_000, SORT_DIRECTIONS), nleg)
         finally:
             ctx.set_walk('quad')
-        log('exact (literal reference) walk: %.3g photons/s on one batch (%.1fx slower than the default walk)' % (
-            exact_rate, (value / world) / exact_rate))
+        exact_walk = rate_stats(walls)
+        exact_walk['kernel'] = 'k_raycast_literal'
+        exact_walk['slower_than_default'] = headline_order['value'] / exact_walk['value']
+        log('exact (literal reference) walk: %.4g +- %.2g photons/s over %d batches (%.1fx slower than the default walk)' % (
+            exact_walk['value'], exact_walk['std'], nleg, exact_walk['slower_than_default']))
 
     # the second kernel of a step, k_physics (main pass): per photon step it reads the hit entry (8 B), the photon's
     # record (64 B) and the winning triangle's record (48 B), writes a survivor's record, next ray and queue slot
@@ -460,33 +520,6 @@ def main():
         per_step = 2.0 * physics_traffic['hbm_bytes_per_launch']
         physics['hbm_measured_GBps'] = per_step * stats.get('physics_launches', 0) / phys_s / 1e9
         physics['traffic_over_algorithmic'] = per_step * stats.get('physics_launches', 0) / phys_bytes_total
-
-    # ---- the same batch with its photons in GENERATION order (round 2's input; one extra batch, not part of `value`)
-    unsorted_rate = unsorted_asis_rate = None
-    if world == 1 and SORT_DIRECTIONS and not os.environ.get('CHROMA_BENCH_NO_EXACT'):
-        b = buffers[0]
-        b.id_base = (20_001 * world + rank) * nphotons
-        pos = (ctypes.c_float * 3)(0.0, 0.0, 0.0)
-        _lib.check(lib.chroma_generate_bomb(ctx.handle, ctypes.byref(b.struct), nphotons, ENGINE_SEED, b.id_base, pos, wl_lo, wl_hi))
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        st_u = {}
-        run_step(b, False, st_u)
-        ctx.synchronize()
-        unsorted_rate = nphotons / (time.perf_counter() - t0)
-        log('photons in generation order (not sorted by direction): %.3g photons/s on one batch' % unsorted_rate)
-        if os.environ.get('CHROMA_BENCH_AUTOSORT'):
-            # (A/B of chroma_set_autosort: the same batch once more, ordered by the engine itself -- an index sort + gather)
-            _lib.check(lib.chroma_generate_bomb(ctx.handle, ctypes.byref(b.struct), nphotons, ENGINE_SEED, b.id_base, pos, wl_lo, wl_hi))
-            ctx.set_autosort('auto')
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            run_step(b, False, st_u)
-            ctx.synchronize()
-            unsorted_asis_rate = nphotons / (time.perf_counter() - t0)
-            ctx.set_autosort('off')
-            log('  the same with chroma_set_autosort(auto): %.3g photons/s (%d photons taken up in direction order by the engine)' % (
-                unsorted_asis_rate, st_u.get('reordered', 0)))
 
     cpu_baseline = None
     if run_cpu:
@@ -549,10 +582,15 @@ def main():
                        'step': 'propagate(max_steps) + channel hit arrays + flat-hit count and compaction' + (' + all-reduce' if world > 1 else ''),
                        'inputs': ('resident in HBM' if resident else 'bomb regenerated on the device inside the timed region (memory)') +
                                  ('; photons in the order of tools.argsort_direction (Morton code of theta, phi), as the reference\'s own '
-                                  'propagate benchmark prepares them before its clock starts (chroma/benchmark.py:80-82)' if SORT_DIRECTIONS else '; photons in generation order (unsorted)'),
+                                  'propagate benchmark prepares them before its clock starts (chroma/benchmark.py:80-82)' if SORT_DIRECTIONS else
+                                  '; photons in generation order (SURVEY.md 8d: the direction pre-sort of chroma/benchmark.py:80-82 is reported separately: config.presorted, config.sort)'),
                        'target_photons_per_s_per_gpu': 2.5e6, 'vs_target': value / world / 2.5e6,
                        'steps_per_photon': steps_pp, 'nodes_per_step': nodes_ps, 'triangle_tests_per_step': tris_ps,
-                       'exact_walk_photons_per_s': exact_rate, 'generation_order_photons_per_s': unsorted_rate, 'generation_order_autosort_photons_per_s': unsorted_asis_rate,
+                       # the three legs, each over the same number of batches with its spread: `value`'s own input order, the other
+                       # order, and the exact walk; what putting a batch in direction order costs (never inside a timed region)
+                       'generation_order': generation, 'presorted': presorted, 'sort': sort_cost, 'exact_walk': exact_walk,
+                       'exact_walk_photons_per_s': exact_walk['value'] if exact_walk else None,
+                       'value_is': 'presorted' if SORT_DIRECTIONS else 'generation_order',
                        'geometry_build_s': t_build, 'geometry_cached': geometry_cached, 'geometry_upload_s': t_upload,
                        'reduction': ('none: one GPU' if world == 1 and not os.environ.get('CHROMA_BENCH_COMM') else
                                      'library RCCL (chroma_allreduce_hits, in place on the device arrays)' if lib_comm else

@@ -39,8 +39,16 @@ def test_bench_line_carries_the_contract():
     # algorithmic bytes per launch over the measured launch time IS `achieved`
     assert abs(r['algorithmic_bytes_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e9 - r['achieved']) < 1e-6 * r['achieved']
     # the exact walk's rate on the same batch, and which reduction path the run took
-    assert 0 < j['config']['exact_walk_photons_per_s'] < j['value'] and j['config']['reduction'].startswith('none')
-    assert j['config']['generation_order_photons_per_s'] > 0 and 'argsort_direction' in j['config']['inputs']
+    assert j['config']['reduction'].startswith('none')
+    # the three legs, each over as many batches as the headline, with their spreads: `value`'s own input order
+    # (generation order: SURVEY.md 8d), the pre-sorted input of chroma/benchmark.py:80-82 with what the sort costs, the exact walk
+    cfg = j['config']
+    assert cfg['value_is'] == 'generation_order' and 'generation order' in cfg['inputs']
+    for leg in ('generation_order', 'presorted', 'exact_walk'):
+        assert cfg[leg]['batches'] == 2 and cfg[leg]['value'] > 0 and cfg[leg]['std'] >= 0 and cfg[leg]['ms_per_batch'] > 0, leg
+    assert abs(cfg['generation_order']['value'] / j['value'] - 1.0) < 0.2          # (the headline loop's own per-step times)
+    assert cfg['sort']['ms_per_batch'] > 0 and cfg['exact_walk']['kernel'] == 'k_raycast_literal'
+    assert 0 < cfg['exact_walk_photons_per_s'] == cfg['exact_walk']['value'] < 1.5 * j['value']
     c = j['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['unit'] == 'photons/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']
 
