@@ -253,7 +253,7 @@ def main():
     # batches resident in HBM before the timed region -- unless that many do not fit: then a small ring of
     # buffers is refilled by the device bomb generator INSIDE the timed region (counted against the result)
     free, total = ctx.mem_get_info()
-    work_bytes = nphotons * (2 * 4 + 2 * 4 + 4 + 64 + 2 * 64) + (1 << 30)        # queues, hit hand-off, ray records, working sets
+    work_bytes = nphotons * (2 * 4 + 2 * 4 + 4 + 2 * 64 + 2 * 64 + 64) + (1 << 30)        # queues, hit hand-off, ray records, working sets, final records
     batch_bytes = nphotons * 64
     sort_scratch = nphotons * 28                               # chroma_photons_sort_direction: codes, indices, radix-sort double buffers, one gathered array
     resident = (nbatches + 1) * batch_bytes + work_bytes + sort_scratch + int(0.12 * nphotons) * 72 < 0.92 * free
@@ -297,24 +297,45 @@ def main():
             hits[2] = empty(cap, np.int32, ctx)
             hit_capacity[0] = cap
 
+    separate_hits = bool(os.environ.get('CHROMA_BENCH_SEPARATE_HITS'))      # (A/B: round 3's four calls instead of the fused one)
+
     def run_step(batch, time_kernels, stats):
         rng = _lib.Rng(ENGINE_SEED, batch.id_base)
         aborted = ctypes.c_int32(0)
         st = _lib.PropagateStats()
-        _lib.check(lib.chroma_propagate(ctx.handle, gg.handle, ctypes.byref(batch.struct), nphotons, 1, rng,
-                                        args.max_steps, 0, 0, int(time_kernels), ctypes.byref(st), ctypes.byref(aborted)))
         counts.fill(np.uint32(0))
         earliest.fill(np.uint32(0x7f800000))
-        _lib.check(lib.chroma_channel_hits(ctx.handle, gg.handle, nphotons, event.SURFACE_DETECT, ctypes.byref(batch.struct),
-                                           counts.ptr, earliest.ptr))
-        # get_flat_hits (chroma/gpu/photon.py:96-175): count, then compact the detected photons + their channels
         nhits = ctypes.c_uint32()
-        _lib.check(lib.chroma_count_photon_hits(ctx.handle, gg.handle, 0, nphotons, event.SURFACE_DETECT,
-                                                ctypes.byref(batch.struct), ctypes.byref(nhits)))
-        ensure_hit_buffers(nhits.value)
         ncopied = ctypes.c_uint32()
-        _lib.check(lib.chroma_copy_photon_hits(ctx.handle, gg.handle, 0, nphotons, event.SURFACE_DETECT, ctypes.byref(batch.struct),
-                                               ctypes.byref(hits[1]), hits[2].ptr, ctypes.byref(ncopied)))
+        if not separate_hits:
+            # propagate_hit as ONE library call (chroma_propagate_hits): the pass that finishes the propagation also makes the
+            # per-channel arrays, counts the hits and compacts them with their channels (get_flat_hits, chroma/gpu/photon.py:96-175)
+            req = _lib.HitsRequest()
+            req.detection_state = event.SURFACE_DETECT
+            req.capacity = hit_capacity[0]
+            req.dst = ctypes.pointer(hits[1])
+            req.d_channels = hits[2].ptr
+            req.d_hit_count = counts.ptr
+            req.d_earliest_time_bits = earliest.ptr
+            _lib.check(lib.chroma_propagate_hits(ctx.handle, gg.handle, ctypes.byref(batch.struct), nphotons, 1, rng,
+                                                 args.max_steps, 0, 0, int(time_kernels), ctypes.byref(st), ctypes.byref(aborted), ctypes.byref(req)))
+            nhits.value = req.nhits
+            ncopied.value = min(req.nhits, req.capacity)
+            if req.nhits > req.capacity:          # (the buffers were sized from the counting pass: not expected)
+                ensure_hit_buffers(req.nhits)
+                _lib.check(lib.chroma_copy_photon_hits(ctx.handle, gg.handle, 0, nphotons, event.SURFACE_DETECT, ctypes.byref(batch.struct),
+                                                       ctypes.byref(hits[1]), hits[2].ptr, ctypes.byref(ncopied)))
+        else:
+            _lib.check(lib.chroma_propagate(ctx.handle, gg.handle, ctypes.byref(batch.struct), nphotons, 1, rng,
+                                            args.max_steps, 0, 0, int(time_kernels), ctypes.byref(st), ctypes.byref(aborted)))
+            _lib.check(lib.chroma_channel_hits(ctx.handle, gg.handle, nphotons, event.SURFACE_DETECT, ctypes.byref(batch.struct),
+                                               counts.ptr, earliest.ptr))
+            # get_flat_hits (chroma/gpu/photon.py:96-175): count, then compact the detected photons + their channels
+            _lib.check(lib.chroma_count_photon_hits(ctx.handle, gg.handle, 0, nphotons, event.SURFACE_DETECT,
+                                                    ctypes.byref(batch.struct), ctypes.byref(nhits)))
+            ensure_hit_buffers(nhits.value)
+            _lib.check(lib.chroma_copy_photon_hits(ctx.handle, gg.handle, 0, nphotons, event.SURFACE_DETECT, ctypes.byref(batch.struct),
+                                                   ctypes.byref(hits[1]), hits[2].ptr, ctypes.byref(ncopied)))
         # the one exchange: per-channel arrays over RCCL, in place on the device (identity on one GPU)
         if lib_comm:
             _lib.check(lib.chroma_allreduce_hits(ctx.handle, counts.ptr, earliest.ptr, nch))
@@ -341,7 +362,7 @@ def main():
     count_n_stats = {}
     ctx.set_counting(True)
     probe = Batch().fill(10_000)
-    ensure_hit_buffers(int(0.10 * nphotons))
+    ensure_hit_buffers(int(0.12 * nphotons) + 65536)
     run_step(probe, False, count_n_stats)
     ctx.set_counting(False)
     steps_pp = count_n_stats['photon_steps'] / nphotons
@@ -579,7 +600,7 @@ def main():
                        'wavelength_nm': [wl_lo, wl_hi] if wl_hi > wl_lo else wl_lo,
                        'engine_seed': ENGINE_SEED, 'parallelism': 'photon shards x%d, geometry replicated, per-channel arrays all-reduced (%s)' % (
                            world, 'RCCL inside the library' if lib_comm else ('torch.distributed, %s' % (backend if world > 1 else '-'))),
-                       'step': 'propagate(max_steps) + channel hit arrays + flat-hit count and compaction' + (' + all-reduce' if world > 1 else ''),
+                       'step': 'propagate(max_steps) + channel hit arrays + flat-hit count and compaction' + (' (one library call: chroma_propagate_hits)' if not separate_hits else ' (four library calls)') + (' + all-reduce' if world > 1 else ''),
                        'inputs': ('resident in HBM' if resident else 'bomb regenerated on the device inside the timed region (memory)') +
                                  ('; photons in the order of tools.argsort_direction (Morton code of theta, phi), as the reference\'s own '
                                   'propagate benchmark prepares them before its clock starts (chroma/benchmark.py:80-82)' if SORT_DIRECTIONS else

@@ -79,6 +79,12 @@ class PropagateStats(Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class HitsRequest(Structure):
+    """chroma_hits_request"""
+    _fields_ = [('detection_state', c_uint32), ('capacity', c_uint32), ('dst', POINTER(PhotonArrays)), ('d_channels', c_void_p),
+                ('d_hit_count', c_void_p), ('d_earliest_time_bits', c_void_p), ('nhits', c_uint32)]
+
+
 class DaqTables(Structure):
     """chroma_daq_tables"""
     _fields_ = [('d_time_cdf_x', c_void_p), ('d_time_cdf_y', c_void_p), ('time_cdf_len', c_int32),
@@ -125,6 +131,8 @@ SIGNATURES = {
     'chroma_intersect_mesh': (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'chroma_propagate': (c_int32, [c_void_p, c_void_p, POINTER(PhotonArrays), c_uint64, c_uint32, Rng, c_int32,
                                    c_int32, c_int32, c_int32, POINTER(PropagateStats), POINTER(c_int32)]),
+    'chroma_propagate_hits': (c_int32, [c_void_p, c_void_p, POINTER(PhotonArrays), c_uint64, c_uint32, Rng, c_int32,
+                                        c_int32, c_int32, c_int32, POINTER(PropagateStats), POINTER(c_int32), POINTER(HitsRequest)]),
     'chroma_channel_hits': (c_int32, [c_void_p, c_void_p, c_uint64, c_uint32, POINTER(PhotonArrays),
                                       c_void_p, c_void_p]),
     'chroma_daq_reset': (c_int32, [c_void_p, c_float, c_uint32, c_void_p, c_void_p, c_void_p]),

@@ -83,7 +83,10 @@ struct chroma_ctx {
     float4 *rays = nullptr;                // [capacity][4] ray records (k_ray_setup / k_load_working / k_physics)
     float4 *rays_b = nullptr;              // the records of the NEXT step while k_physics writes them (default walk)
     float4 *work_a = nullptr, *work_b = nullptr;    // [capacity][4] the dense working sets that go with queue_a / queue_b
-    float4 *final_rec = nullptr; uint32_t final_epoch = 0;      // (PHYS_ENDED_AOS experiment)
+    // chroma_propagate_hits: photons that end in k_physics leave as one 64-byte record at their id (final_rec, stamped with the
+    // call's epoch); k_finalize_hits fills the caller's arrays from the records and extracts the hits in one pass
+    float4 *final_rec = nullptr; size_t final_capacity = 0; uint32_t final_epoch = 0;
+    float4 *final_use = nullptr;           // final_rec while a call uses the records, else NULL (k_physics stores to the arrays)
     // small device scratch: [0..3] DeviceCounters, then misc words
     DeviceCounters *d_counters = nullptr;
     uint32_t *d_words = nullptr;        // 16 words
@@ -2131,9 +2134,6 @@ k_raycast_retry(GeoView g, const float4 *rays, const StepState *st,
 #define PHYS_PLAIN_BLOCK 256        // -2 ms per C3 step against 512 threads at 4 waves (profiles/r03/ab_physics_occupancy.txt)
 #endif
 #define PHYS_BLOCK_OF(FULL) ((FULL) ? PHYS_BLOCK : PHYS_PLAIN_BLOCK)
-#ifndef PHYS_ENDED_AOS
-#define PHYS_ENDED_AOS 0     // experiment (profiles/r03/ab_physics_ended_aos.txt): a photon that ends in k_physics goes as ONE 64-byte
-#endif                       // record to final[photon id] and a streaming kernel fills the caller's ten arrays at the end of the call
 #ifndef PHYS_STAGE_LDS
 #define PHYS_STAGE_LDS 0     // experiment: survivors' records through LDS as in k_load_working -- no gain here (profiles/r03/ab_lds_staged_stores.txt)
 #endif
@@ -2268,23 +2268,25 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
             counter = rng.counter;
             alive = (p.history & CHROMA_TERMINAL_MASK) == 0;
             if (!alive) {
-#if PHYS_ENDED_AOS
-                float4 *f = final_rec + 4 * (size_t)photon_id;
-                f[0] = make_float4(p.position.x, p.position.y, p.position.z, p.wavelength);
-                f[1] = make_float4(p.direction.x, p.direction.y, p.direction.z, p.time);
-                f[2] = make_float4(p.polarization.x, p.polarization.y, p.polarization.z, p.weight);
-                f[3] = make_float4(__uint_as_float(p.history), __uint_as_float(counter), __int_as_float(p.last_hit_triangle), __uint_as_float(epoch));
-#else
-                pv.rng_counters[photon_id] = counter;
-                store3(pv.pos, photon_id, p.position);
-                store3(pv.dir, photon_id, p.direction);
-                store3(pv.pol, photon_id, p.polarization);
-                pv.wavelengths[photon_id] = p.wavelength;
-                pv.t[photon_id] = p.time;
-                pv.flags[photon_id] = p.history;
-                pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
-                pv.weights[photon_id] = p.weight;
-#endif
+                if (final_rec) {
+                    // (chroma_propagate_hits: one 64-byte record at the photon's id -- a full sector instead of fifteen scattered
+                    //  4-byte stores; k_finalize_hits fills the caller's arrays from it in a streaming pass and extracts the hits)
+                    float4 *f = final_rec + 4 * (size_t)photon_id;
+                    f[0] = make_float4(p.position.x, p.position.y, p.position.z, p.wavelength);
+                    f[1] = make_float4(p.direction.x, p.direction.y, p.direction.z, p.time);
+                    f[2] = make_float4(p.polarization.x, p.polarization.y, p.polarization.z, p.weight);
+                    f[3] = make_float4(__uint_as_float(p.history), __uint_as_float(counter), __int_as_float(p.last_hit_triangle), __uint_as_float(epoch));
+                } else {
+                    pv.rng_counters[photon_id] = counter;
+                    store3(pv.pos, photon_id, p.position);
+                    store3(pv.dir, photon_id, p.direction);
+                    store3(pv.pol, photon_id, p.polarization);
+                    pv.wavelengths[photon_id] = p.wavelength;
+                    pv.t[photon_id] = p.time;
+                    pv.flags[photon_id] = p.history;
+                    pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
+                    pv.weights[photon_id] = p.weight;
+                }
             }
         }
     }
@@ -2653,28 +2655,6 @@ __global__ void k_store_working(GeoView g, PhotonView pv, const uint32_t *queue,
     }
 }
 
-#if PHYS_ENDED_AOS
-// the photons that ended in k_physics during this call (their record carries the call's epoch): to the caller's arrays
-__global__ __launch_bounds__(256) void k_store_final(PhotonView pv, const float4 *final_rec, uint64_t n, uint32_t epoch)
-{
-    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (uint64_t)gridDim.x * blockDim.x) {
-        const float4 *f = final_rec + 4 * id;
-        const float4 f3 = f[3];
-        if (__float_as_uint(f3.w) != epoch) continue;
-        const float4 f0 = f[0], f1 = f[1], f2 = f[2];
-        store3(pv.pos, id, mk3(f0.x, f0.y, f0.z));
-        store3(pv.dir, id, mk3(f1.x, f1.y, f1.z));
-        store3(pv.pol, id, mk3(f2.x, f2.y, f2.z));
-        pv.wavelengths[id] = f0.w;
-        pv.t[id] = f1.w;
-        pv.weights[id] = f2.w;
-        pv.flags[id] = __float_as_uint(f3.x);
-        pv.rng_counters[id] = __float_as_uint(f3.y);
-        pv.last_hit_triangles[id] = __float_as_int(f3.z);
-    }
-}
-#endif
-
 // initial queue of GPUPhotons.propagate (chroma/gpu/photon.py:206-216): slot 0 unused counter,
 // then photon ids with the ncopies clones of a photon next to each other.
 __global__ void k_init_queue(uint32_t *queue, uint64_t n, uint32_t ncopies, uint32_t true_n)
@@ -2888,6 +2868,131 @@ __global__ void k_channel_hits(GeoView g, const uint32_t *flags, const int32_t *
     } else if (ch >= 0) {
         atomicAdd(&hit_count[ch], 1u);
         if (earliest) atomicMin(&earliest[ch], tb);
+    }
+}
+
+// ---- the end of a chroma_propagate_hits call: ONE pass over the photons ---------------------------------------------------
+// What the reference does in four passes after propagate -- the abort-flag reduction (gpu/photon.py:254), count_photon_hits,
+// copy_photon_hits (propagate.cu:147-214) and, for the detector's channel arrays, a DAQ-like reduction -- happens here while a
+// photon's final state is in registers anyway: a photon that ended in k_physics during this call left a 64-byte record at
+// final_rec[id] (stamped with the call's epoch), which is unpacked into the caller's ten arrays (coalesced: every array gets
+// whole lines); any other photon (terminal before the call, finished by the tail kernel, or still alive at max_steps) is read
+// from the arrays.  Detected photons that belong to a channel are counted, compacted into `dst` with their
+// channel (one atomic per block of COPY_ITEMS * 256 photons, as k_copy_hits: the order of the blocks is the order of their atomics), and bump the per-channel count / earliest-time arrays.
+// final_rec == NULL: everything comes from the arrays (the fused form of k_count_hits + k_copy_hits + k_channel_hits).
+struct HitsOut {
+    PhotonView dst; int32_t *channels; uint32_t capacity;
+    uint32_t *hit_count, *earliest;
+    uint32_t detection_state; int want;
+};
+__global__ __launch_bounds__(256) void
+k_finalize_hits(GeoView g, PhotonView pv, const float4 *final_rec, uint32_t epoch, uint64_t n, HitsOut h,
+                uint32_t *words /* [0] number of hits, [2] OR of the NAN_ABORT bits */)
+{
+    __shared__ uint32_t s_wave[256 / WAVE + 1];
+    const long long base = (long long)blockIdx.x * (COPY_ITEMS * 256);
+    const unsigned lane = lane_id(), wave = threadIdx.x / WAVE;
+    int ch[COPY_ITEMS];
+    uint32_t mine = 0, from_record = 0, aborts = 0;
+#pragma unroll
+    for (int k = 0; k < COPY_ITEMS; k++) {
+        const long long id = base + (long long)k * 256 + threadIdx.x;
+        ch[k] = -1;
+        uint32_t tb = 0xFFFFFFFFu;
+        if (id < (long long)n) {
+            uint32_t flags; int lh = -1; float t = 0.f;
+            bool have = false;
+            float4 f3 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (final_rec) { f3 = final_rec[4 * (size_t)id + 3]; have = __float_as_uint(f3.w) == epoch; }
+            if (have) {
+                const float4 *f = final_rec + 4 * (size_t)id;
+                const float4 f0 = f[0], f1 = f[1], f2 = f[2];
+                store3(pv.pos, (size_t)id, mk3(f0.x, f0.y, f0.z));
+                store3(pv.dir, (size_t)id, mk3(f1.x, f1.y, f1.z));
+                store3(pv.pol, (size_t)id, mk3(f2.x, f2.y, f2.z));
+                pv.wavelengths[id] = f0.w;
+                pv.t[id] = f1.w;
+                pv.weights[id] = f2.w;
+                flags = __float_as_uint(f3.x);
+                pv.flags[id] = flags;
+                pv.rng_counters[id] = __float_as_uint(f3.y);
+                lh = __float_as_int(f3.z);
+                pv.last_hit_triangles[id] = lh;
+                t = f1.w;
+                from_record |= 1u << k;
+            } else {
+                flags = pv.flags[id];
+                if (h.want && (flags & h.detection_state)) { lh = pv.last_hit_triangles[id]; t = pv.t[id]; }
+            }
+            aborts |= flags & CHROMA_NAN_ABORT;
+            if (h.want) {
+                ch[k] = hit_channel(g, flags, lh, h.detection_state);
+                if (ch[k] >= 0) { mine++; tb = __float_as_uint(t); }
+            }
+        }
+        if (h.want && h.hit_count) {
+            // (the hits of a wave that fall on ONE channel are added with one atomic: see k_channel_hits)
+            const int c = ch[k];
+            const unsigned long long hitters = __ballot(c >= 0);
+            if (hitters) {
+                const int first = __builtin_amdgcn_readlane(c, (int)__builtin_ctzll(hitters));
+                if (__ballot(c >= 0 && c != first) == 0ull) {
+                    uint32_t m = tb;
+                    for (int off = 32; off > 0; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off));
+                    if (lane == (unsigned)__builtin_ctzll(hitters)) {
+                        atomicAdd(&h.hit_count[first], (uint32_t)__popcll(hitters));
+                        if (h.earliest) atomicMin(&h.earliest[first], m);
+                    }
+                } else if (c >= 0) {
+                    atomicAdd(&h.hit_count[c], 1u);
+                    if (h.earliest) atomicMin(&h.earliest[c], tb);
+                }
+            }
+        }
+    }
+    if (__ballot(aborts != 0u)) {
+        for (int off = 32; off > 0; off >>= 1) aborts |= __shfl_down(aborts, off);
+        if (lane == 0 && aborts) atomicOr(words + 2, aborts);
+    }
+    if (!h.want) return;
+    // exclusive prefix of `mine` over the block: wave scan, then the waves' totals through LDS (as k_copy_hits)
+    uint32_t incl = mine;
+    for (int off = 1; off < WAVE; off <<= 1) { uint32_t v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
+    if (lane == WAVE - 1) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (unsigned w = 0; w < 256 / WAVE; w++) { uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
+        s_wave[256 / WAVE] = total ? atomicAdd(words, total) : 0u;
+    }
+    __syncthreads();
+    if (!h.channels) return;
+    uint32_t off = s_wave[256 / WAVE] + s_wave[wave] + incl - mine;
+#pragma unroll
+    for (int k = 0; k < COPY_ITEMS; k++) {
+        if (ch[k] >= 0) {
+            if (off < h.capacity) {
+                const size_t id = (size_t)(base + (long long)k * 256 + threadIdx.x);
+                if (from_record & (1u << k)) {
+                    // (64 contiguous bytes instead of nine sparse reads of the arrays just written)
+                    const float4 *f = final_rec + 4 * id;
+                    const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
+                    store3(h.dst.pos, off, mk3(f0.x, f0.y, f0.z));
+                    store3(h.dst.dir, off, mk3(f1.x, f1.y, f1.z));
+                    store3(h.dst.pol, off, mk3(f2.x, f2.y, f2.z));
+                    h.dst.wavelengths[off] = f0.w;
+                    h.dst.t[off] = f1.w;
+                    h.dst.flags[off] = __float_as_uint(f3.x);
+                    h.dst.last_hit_triangles[off] = __float_as_int(f3.z);
+                    h.dst.weights[off] = f2.w;
+                    h.dst.evidx[off] = pv.evidx[id];
+                } else {
+                    copy_photon(pv, id, h.dst, off);
+                }
+                h.channels[off] = ch[k];
+            }
+            off++;
+        }
     }
 }
 
@@ -3331,11 +3436,11 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
         else if (geom->view.plain_optics != 0)
             hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK_OF(false)), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                                ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                               ctx->retry_list, 2, pc, (float4 *)nullptr, ctx->final_rec, ctx->final_epoch);
+                               ctx->retry_list, 2, pc, (float4 *)nullptr, ctx->final_use, ctx->final_epoch);
         else
             hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                                ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                               ctx->retry_list, 2, pc, (float4 *)nullptr, ctx->final_rec, ctx->final_epoch);
+                               ctx->retry_list, 2, pc, (float4 *)nullptr, ctx->final_use, ctx->final_epoch);
         if (ev) { HIP_TRY(hipEventRecord(ev[4], ctx->stream)); HIP_TRY(hipEventRecord(ev[2], ctx->stream)); }
         HIP_TRY(hipGetLastError());
         return CHROMA_OK;
@@ -3410,7 +3515,7 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
 #undef RAYCAST_LAUNCH
     // physics for every slot whose hit is regular; then the strict walk and the physics of the rest
     const bool plain = geom->view.plain_optics != 0;      // (no re-emitting component, default surface model only)
-    const bool deal = PHYS_DEAL != 0 && PHYS_ENDED_AOS == 0 && plain;          // (photons of a block dealt by what happens to them: k_physics_deal)
+    const bool deal = PHYS_DEAL != 0 && plain && !ctx->final_use;          // (photons of a block dealt by what happens to them: k_physics_deal)
     const int pb = deal ? PHYS_DEAL_BLOCK : PHYS_BLOCK_OF(!plain);
     unsigned pblocks = (unsigned)std::min<long long>((n_upper + pb - 1) / pb, std::max<long long>(1, (long long)ctx->physics_blocks * PHYS_BLOCK / pb));
     DeviceCounters *pc = ctx->counting ? ctx->d_counters : nullptr;
@@ -3421,11 +3526,11 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     else if (plain)
         hipLaunchKernelGGL((k_physics<false>), dim3(pblocks), dim3(PHYS_BLOCK_OF(false)), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                            ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                           ctx->retry_list, 0, pc, rays_next, ctx->final_rec, ctx->final_epoch);
+                           ctx->retry_list, 0, pc, rays_next, ctx->final_use, ctx->final_epoch);
     else
         hipLaunchKernelGGL((k_physics<true>), dim3(pblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                            ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                           ctx->retry_list, 0, pc, rays_next, ctx->final_rec, ctx->final_epoch);
+                           ctx->retry_list, 0, pc, rays_next, ctx->final_use, ctx->final_epoch);
     if (ev) HIP_TRY(hipEventRecord(ev[4], ctx->stream));          // end of the main physics pass
     // (both passes stride over the list and leave at once when it is short -- the usual case -- but a plain geometry
     //  with faces on the world box lists a good part of its hits for the exact check: grids for that)
@@ -3446,11 +3551,11 @@ static int launch_split_step(chroma_ctx *ctx, chroma_geometry *geom, PhotonView 
     else if (plain)
         hipLaunchKernelGGL((k_physics<false>), dim3(fblocks), dim3(PHYS_BLOCK_OF(false)), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
                            work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
-                           scatter_first, ctx->retry_list, 1, pc, rays_next, ctx->final_rec, ctx->final_epoch);
+                           scatter_first, ctx->retry_list, 1, pc, rays_next, ctx->final_use, ctx->final_epoch);
     else
         hipLaunchKernelGGL((k_physics<true>), dim3(fblocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q,
                            work_out, ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights,
-                           scatter_first, ctx->retry_list, 1, pc, rays_next, ctx->final_rec, ctx->final_epoch);
+                           scatter_first, ctx->retry_list, 1, pc, rays_next, ctx->final_use, ctx->final_epoch);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(hipGetLastError());
     if (chained) std::swap(ctx->rays, ctx->rays_b);       // (what k_physics wrote is the next step's input)
@@ -4563,13 +4668,6 @@ static int ensure_queues(chroma_ctx *ctx, size_t n)
     HIP_TRY(ctx_malloc(ctx, (void **)&ctx->rays_b, (n + 1) * 4 * sizeof(float4)));
     HIP_TRY(ctx_malloc(ctx, (void **)&ctx->work_a, (n + 1) * 4 * sizeof(float4)));
     HIP_TRY(ctx_malloc(ctx, (void **)&ctx->work_b, (n + 1) * 4 * sizeof(float4)));
-#if PHYS_ENDED_AOS
-    if (ctx->final_rec) hipFree(ctx->final_rec);
-    ctx->final_rec = nullptr;
-    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->final_rec, (n + 1) * 4 * sizeof(float4)));
-    HIP_TRY(hipMemset(ctx->final_rec, 0, (n + 1) * 4 * sizeof(float4)));
-    ctx->final_epoch = 0;
-#endif
     ctx->queue_capacity = n + 1;
     return CHROMA_OK;
 }
@@ -4699,12 +4797,33 @@ static int propagate_order(chroma_ctx *ctx, const PhotonView &pv, uint64_t nphot
     return CHROMA_OK;
 }
 
-int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon_arrays *photons, uint64_t nphotons,
-                     uint32_t ncopies, chroma_rng rng, int32_t max_steps, int32_t use_weights, int32_t scatter_first,
-                     int32_t time_kernels, chroma_propagate_stats *stats, int32_t *aborted)
+// the photons' final records (chroma_propagate_hits): 64 bytes per photon of the largest batch seen, zeroed once -- a record
+// belongs to a call when it carries that call's epoch, and epochs start at 1
+static int ensure_final_records(chroma_ctx *ctx, size_t n)
+{
+    if (ctx->final_capacity >= n) return CHROMA_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->final_rec) hipFree(ctx->final_rec);
+    ctx->final_rec = nullptr; ctx->final_capacity = 0;
+    HIP_TRY(ctx_malloc(ctx, (void **)&ctx->final_rec, n * 4 * sizeof(float4)));
+    HIP_TRY(hipMemsetAsync(ctx->final_rec, 0, n * 4 * sizeof(float4), ctx->stream));
+    ctx->final_capacity = n;
+    ctx->final_epoch = 0;
+    return CHROMA_OK;
+}
+
+static int propagate_impl(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon_arrays *photons, uint64_t nphotons,
+                          uint32_t ncopies, chroma_rng rng, int32_t max_steps, int32_t use_weights, int32_t scatter_first,
+                          int32_t time_kernels, chroma_propagate_stats *stats, int32_t *aborted, chroma_hits_request *hr)
 {
     if (!ctx || !geom) return set_error(CHROMA_ERR_INVALID, "bad argument");
     int rc = check_photons(photons, true); if (rc) return rc;
+    if (hr) {
+        hr->nhits = 0;
+        if (!geom->view.nsolids) return set_error(CHROMA_ERR_INVALID, "geometry has no detector channel map");
+        if (hr->dst) { rc = check_photons(hr->dst, false); if (rc) return rc; }
+        if ((hr->dst != nullptr) != (hr->d_channels != nullptr)) return set_error(CHROMA_ERR_INVALID, "flat hits need both dst and d_channels");
+    }
     if (nphotons >= 0x7fffffffull) return set_error(CHROMA_ERR_INVALID, "at most 2^31-2 photons per call");
     if (ncopies == 0 || nphotons % ncopies) return set_error(CHROMA_ERR_INVALID, "nphotons must be a multiple of ncopies");
     if (aborted) *aborted = 0;
@@ -4714,6 +4833,20 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     PhotonView pv = to_view(photons);
     uint32_t *in_q = ctx->queue_a, *out_q = ctx->queue_b;
     float4 *work_in = ctx->work_a, *work_out = ctx->work_b;
+    // (final records: with a hit request, or for every call under CHROMA_FINAL_RECORDS=1 -- an A/B switch)
+    static const bool records_always = getenv("CHROMA_FINAL_RECORDS") && atoi(getenv("CHROMA_FINAL_RECORDS")) != 0;
+    const bool use_records = (hr != nullptr || records_always) && ctx->split_tail != 0;
+    ctx->final_use = nullptr;
+    if (use_records) {
+        rc = ensure_final_records(ctx, nphotons); if (rc) return rc;
+        ctx->final_epoch++;
+        if (ctx->final_epoch == 0u) {            // (wrapped: no stale record may look current)
+            HIP_TRY(hipMemsetAsync(ctx->final_rec, 0, ctx->final_capacity * 4 * sizeof(float4), ctx->stream));
+            ctx->final_epoch = 1u;
+        }
+        ctx->final_use = ctx->final_rec;
+    }
+    struct FinalGuard { chroma_ctx *c; ~FinalGuard() { c->final_use = nullptr; } } final_guard{ctx};
 
     double kernel_ms = 0.0, raycast_ms = 0.0, physics_ms = 0.0, packet_ms = 0.0;
     uint64_t launches = 0, raycast_launches = 0, physics_launches = 0, packet_launches = 0;
@@ -4730,9 +4863,6 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
     // fused tail kernel.  The live photons travel in the dense working set (k_load_working).
     const bool device_steps = ctx->split_tail != 0;
     if (device_steps) {
-#if PHYS_ENDED_AOS
-        ctx->final_epoch++;
-#endif
         HIP_TRY(hipMemsetAsync(ctx->d_step, 0, sizeof(StepState), ctx->stream));
         hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, in_q, 1u);
         hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, out_q, 1u);
@@ -4799,12 +4929,6 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
             unsigned blocks = (unsigned)std::min<long long>((n_upper + 255) / 256, 4096);
             hipLaunchKernelGGL(k_store_working, dim3(std::max(blocks, 1u)), dim3(256), 0, ctx->stream, geom->view, pv, in_q, work_in);
         }
-#if PHYS_ENDED_AOS
-        {
-            unsigned blocks = (unsigned)std::min<uint64_t>((nphotons + 255) / 256, 8192);
-            hipLaunchKernelGGL(k_store_final, dim3(blocks), dim3(256), 0, ctx->stream, pv, ctx->final_rec, (uint64_t)nphotons, ctx->final_epoch);
-        }
-#endif
         HIP_TRY(hipMemcpyAsync(ctx->h_step, ctx->d_step, sizeof(StepState), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         launches = ((const StepState *)ctx->h_step)->launches;
@@ -4860,16 +4984,36 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
             }
         }
     }
-    // abort warning word (photon.py:254-255)
-    HIP_TRY(hipMemsetAsync(ctx->d_words + 2, 0, 4, ctx->stream));
-    {
-        unsigned blocks = (unsigned)std::min<uint64_t>((nphotons + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_flags_or, dim3(blocks), dim3(256), 0, ctx->stream, photons->flags, (uint64_t)nphotons,
-                           CHROMA_NAN_ABORT, ctx->d_words + 2);
-        HIP_TRY(hipGetLastError());
-    }
     uint32_t word = 0;
-    rc = read_word(ctx, 2, &word); if (rc) return rc;
+    if (use_records || hr) {
+        // one pass: records -> the caller's arrays, abort word, hit count + compaction + per-channel arrays (k_finalize_hits)
+        HitsOut ho; memset(&ho, 0, sizeof ho);
+        if (hr) {
+            ho.want = 1;
+            ho.detection_state = hr->detection_state;
+            if (hr->dst) { ho.dst = to_view(hr->dst); ho.channels = hr->d_channels; ho.capacity = hr->capacity; }
+            ho.hit_count = hr->d_hit_count; ho.earliest = hr->d_hit_count ? hr->d_earliest_time_bits : nullptr;
+        }
+        HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 12, ctx->stream));
+        const unsigned blocks = (unsigned)((nphotons + COPY_ITEMS * 256 - 1) / (COPY_ITEMS * 256));
+        hipLaunchKernelGGL(k_finalize_hits, dim3(blocks), dim3(256), 0, ctx->stream, geom->view, pv, (const float4 *)ctx->final_use, ctx->final_epoch,
+                           (uint64_t)nphotons, ho, ctx->d_words);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctx->h_words, ctx->d_words, 12, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        word = ctx->h_words[2];
+        if (hr) hr->nhits = ctx->h_words[0];
+    } else {
+        // abort warning word (photon.py:254-255)
+        HIP_TRY(hipMemsetAsync(ctx->d_words + 2, 0, 4, ctx->stream));
+        {
+            unsigned blocks = (unsigned)std::min<uint64_t>((nphotons + 255) / 256, 4096);
+            hipLaunchKernelGGL(k_flags_or, dim3(blocks), dim3(256), 0, ctx->stream, photons->flags, (uint64_t)nphotons,
+                               CHROMA_NAN_ABORT, ctx->d_words + 2);
+            HIP_TRY(hipGetLastError());
+        }
+        rc = read_word(ctx, 2, &word); if (rc) return rc;
+    }
     if (aborted) *aborted = (word & CHROMA_NAN_ABORT) ? 1 : 0;
     if (stats) {
         rc = chroma_propagate_stats_read(ctx, stats); if (rc) return rc;
@@ -4889,6 +5033,21 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
         if (tmp.stack_overflows) return set_error(CHROMA_ERR_STACK, "traversal stack overflowed for %llu rays", (unsigned long long)tmp.stack_overflows);
     }
     return CHROMA_OK;
+}
+
+int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon_arrays *photons, uint64_t nphotons,
+                     uint32_t ncopies, chroma_rng rng, int32_t max_steps, int32_t use_weights, int32_t scatter_first,
+                     int32_t time_kernels, chroma_propagate_stats *stats, int32_t *aborted)
+{
+    return propagate_impl(ctx, geom, photons, nphotons, ncopies, rng, max_steps, use_weights, scatter_first, time_kernels, stats, aborted, nullptr);
+}
+
+int chroma_propagate_hits(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon_arrays *photons, uint64_t nphotons,
+                          uint32_t ncopies, chroma_rng rng, int32_t max_steps, int32_t use_weights, int32_t scatter_first,
+                          int32_t time_kernels, chroma_propagate_stats *stats, int32_t *aborted, chroma_hits_request *hits)
+{
+    if (!hits) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    return propagate_impl(ctx, geom, photons, nphotons, ncopies, rng, max_steps, use_weights, scatter_first, time_kernels, stats, aborted, hits);
 }
 
 int chroma_channel_hits(chroma_ctx *ctx, chroma_geometry *geom, uint64_t nphotons, uint32_t detection_state,

@@ -191,6 +191,62 @@ class GPUPhotons(object):
         return step_photon_ids, step_photons
 
     @profile_if_possible
+    def propagate_hits(self, gpu_detector, rng_states, max_steps=10, use_weights=False, scatter_first=0, target_flag=(0x1 << 2),
+                       capacity=None, channel_arrays=None, stats=None, time_kernels=False, exact=False,
+                       nthreads_per_block=64, max_blocks=1024):
+        """``propagate`` followed by ``get_flat_hits`` as ONE library call (chroma_propagate_hits): the pass that finishes
+        the propagation also counts and compacts the detected photons with their channels (chroma/gpu/photon.py:96-175) and,
+        when ``channel_arrays=(counts, earliest)`` (device arrays of nchannels uint32) is given, accumulates the per-channel
+        hit count and earliest time into them.  Returns what ``get_flat_hits`` would return after ``propagate`` (the same set of photons;
+        their order is unspecified, as in the reference).  ``capacity``: room for that many flat hits (default: a quarter of the photons, at least
+        65 536); should more be detected, the full set is fetched with ``get_flat_hits`` afterwards."""
+        if exact and self.ctx.walk != 'literal':
+            previous = self.ctx.walk
+            self.ctx.set_walk('literal')
+            try:
+                return self.propagate_hits(gpu_detector, rng_states, max_steps, use_weights, scatter_first, target_flag, capacity,
+                                           channel_arrays, stats, time_kernels)
+            finally:
+                self.ctx.set_walk(previous)
+        nphotons = self.pos.size
+        lib, ctx = self.ctx._lib, self.ctx
+        if capacity is None:
+            capacity = min(nphotons, max(65536, nphotons // 4))
+        capacity = int(max(capacity, 1))
+        out = GPUPhotonsSlice(**_alloc_fields(capacity, ctx))
+        channels = empty(capacity, np.int32, ctx)
+        dst = _structure(out)
+        s = _structure(self)
+        req = _lib.HitsRequest()
+        req.detection_state = int(target_flag)
+        req.capacity = capacity
+        req.dst = ctypes.pointer(dst)
+        req.d_channels = channels.ptr
+        if channel_arrays is not None:
+            req.d_hit_count = channel_arrays[0].ptr
+            req.d_earliest_time_bits = channel_arrays[1].ptr if channel_arrays[1] is not None else None
+        st = _lib.PropagateStats()
+        aborted = ctypes.c_int32(0)
+        _lib.check(lib.chroma_propagate_hits(ctx.handle, gpu_detector.handle, ctypes.byref(s), nphotons, self.ncopies,
+                                             self._rng(rng_states), int(max_steps), int(bool(use_weights)), int(scatter_first),
+                                             int(bool(time_kernels)), ctypes.byref(st), ctypes.byref(aborted), ctypes.byref(req)))
+        if stats is not None:
+            for k, v in st.as_dict().items():
+                stats[k] = stats.get(k, 0) + v
+            stats['nhits'] = stats.get('nhits', 0) + int(req.nhits)
+        if aborted.value:
+            print("WARNING: ABORTED PHOTONS", file=sys.stderr)
+        n = int(req.nhits)
+        if n > capacity:
+            return self.get_flat_hits(gpu_detector, target_flag=target_flag)
+        w = slice(0, n)
+        p = GPUPhotonsSlice(pos=out.pos[w], dir=out.dir[w], pol=out.pol[w], wavelengths=out.wavelengths[w], t=out.t[w],
+                            last_hit_triangles=out.last_hit_triangles[w], flags=out.flags[w], weights=out.weights[w],
+                            evidx=out.evidx[w], rng_counters=out.rng_counters[w]).get()
+        p.channel = channels[w].get().astype(np.uint32) if n else np.zeros(0, dtype=np.uint32)
+        return p
+
+    @profile_if_possible
     def copy_queue(self, queue_gpu, nphotons, nthreads_per_block=64, max_blocks=1024, start_photon=0):
         """Gather the photons listed in ``queue_gpu`` (tracking mode, photon.py:261-285)."""
         f = _alloc_fields(nphotons, self.ctx)

@@ -73,17 +73,24 @@ class Simulation(object):
             uploaded = self._upload_batch(batch_events, upload=False)
         gpu_photons, bounds = uploaded
         t_copy = timer()
-        tracking = gpu_photons.propagate(self.gpu_geometry, self.rng_states,
-                                         nthreads_per_block=self.nthreads_per_block, max_blocks=self.max_blocks,
-                                         max_steps=max_steps, track=self.photon_tracking, exact=self.exact)
+        is_detector = hasattr(self.detector, 'num_channels')
+        want_hits = is_detector and (keep_hits or keep_flat_hits)
+        batch_hits = tracking = None
+        if want_hits and not self.photon_tracking:
+            # propagate + get_flat_hits as one library call (chroma_propagate_hits): the same set of hits
+            batch_hits = gpu_photons.propagate_hits(self.gpu_geometry, self.rng_states, max_steps=max_steps, exact=self.exact)
+        else:
+            tracking = gpu_photons.propagate(self.gpu_geometry, self.rng_states,
+                                             nthreads_per_block=self.nthreads_per_block, max_blocks=self.max_blocks,
+                                             max_steps=max_steps, track=self.photon_tracking, exact=self.exact)
         t_prop = timer()
         if verbose:
             print('GPU copy took %0.2f s' % (t_copy - t_start))
             print('GPU propagate took %0.2f s' % (t_prop - t_copy))
 
-        is_detector = hasattr(self.detector, 'num_channels')
         batch_end = gpu_photons.get() if keep_photons_end else None
-        batch_hits = gpu_photons.get_flat_hits(self.gpu_geometry) if is_detector and (keep_hits or keep_flat_hits) else None
+        if want_hits and batch_hits is None:
+            batch_hits = gpu_photons.get_flat_hits(self.gpu_geometry)
 
         # the hits of each event: one stable sort by event index and slices of it (views) instead of one boolean mask
         # over all hits per event (chroma/sim.py:118-121 does the latter: quadratic in the number of events)

@@ -279,6 +279,33 @@ int chroma_propagate(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon
                      int32_t max_steps, int32_t use_weights, int32_t scatter_first,
                      int32_t time_kernels, chroma_propagate_stats *stats, int32_t *aborted);
 
+/* propagate_hit in ONE call: chroma_propagate followed -- in the same pass that finishes the propagation -- by what the
+ * reference does afterwards in separate kernels: the abort-flag reduction (chroma/gpu/photon.py:254-255), `count_photon_hits`
+ * + `copy_photon_hits` (chroma/cuda/propagate.cu:147-214, GPUPhotons.get_flat_hits, chroma/gpu/photon.py:96-175) and the
+ * per-channel hit count / earliest time of chroma_channel_hits.  Photons that end during the call travel as one 64-byte
+ * record each and a single streaming kernel fills the caller's arrays from them while it extracts the hits; the arrays end up
+ * exactly as chroma_propagate leaves them, and the flat hits are the SET chroma_copy_photon_hits would copy afterwards (their order
+ * is unspecified, as in the reference: blocks of 4096 photons land in the order their atomics do) -- tests/test_gpu_hits.py.
+ *   dst / d_channels   device arrays for up to `capacity` flat hits and their channels (both or neither)
+ *   d_hit_count, d_earliest_time_bits   per-channel arrays (device, nchannels), ACCUMULATED into as by chroma_channel_hits;
+ *                      d_hit_count may be NULL (then neither is touched), d_earliest_time_bits may be NULL
+ *   nhits (out)        detected photons that belong to a channel; if it exceeds `capacity` only `capacity` of them were
+ *                      written -- the photon arrays are final, chroma_copy_photon_hits with larger buffers gets all */
+typedef struct chroma_hits_request {
+    uint32_t detection_state;
+    uint32_t capacity;
+    const chroma_photon_arrays *dst;
+    int32_t *d_channels;
+    uint32_t *d_hit_count;
+    uint32_t *d_earliest_time_bits;
+    uint32_t nhits;
+} chroma_hits_request;
+int chroma_propagate_hits(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon_arrays *photons,
+                          uint64_t nphotons, uint32_t ncopies, chroma_rng rng,
+                          int32_t max_steps, int32_t use_weights, int32_t scatter_first,
+                          int32_t time_kernels, chroma_propagate_stats *stats, int32_t *aborted,
+                          chroma_hits_request *hits);
+
 /* Per-channel reduction of detected photons: hit count and earliest hit time
  * (float bits, valid for t >= 0 as in chroma/cuda/daq.cu:5-20).  The arrays
  * (length nchannels, device) are ACCUMULATED into: zero / 0x7f800000-fill them first.
