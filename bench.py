@@ -56,8 +56,10 @@ def kernel_source_hash():
     """Identifies the kernels a profile was taken with: profiles/pmc_traffic.json entries carry it, and a
     counter figure is only quoted when it belongs to the sources this run was built from."""
     h = hashlib.sha256()
-    for name in ('chroma_hip.hip', 'propagate_device.h', 'device_common.h'):
-        with open(os.path.join(ROOT, 'chroma_amd', 'csrc', name), 'rb') as f:
+    csrc = os.path.join(ROOT, 'chroma_amd', 'csrc')
+    names = ['chroma_hip.hip', 'propagate_device.h', 'device_common.h'] + sorted(n for n in os.listdir(csrc) if n.startswith(('kernel_', 'kernels_')) and n.endswith('.h'))
+    for name in names:
+        with open(os.path.join(csrc, name), 'rb') as f:
             h.update(f.read())
     with open(os.path.join(ROOT, 'include', 'chroma_math.h'), 'rb') as f:
         h.update(f.read())

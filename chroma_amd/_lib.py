@@ -85,6 +85,15 @@ class HitsRequest(Structure):
                 ('d_hit_count', c_void_p), ('d_earliest_time_bits', c_void_p), ('nhits', c_uint32)]
 
 
+class PropagateOptions(Structure):
+    """chroma_propagate_options: what ONE call does (-1: the context's setting)"""
+    _fields_ = [('max_steps', c_int32), ('use_weights', c_int32), ('scatter_first', c_int32), ('time_kernels', c_int32),
+                ('walk', c_int32), ('tail', c_int32), ('counting', c_int32), ('reserved', c_int32 * 5)]
+
+    def __init__(self, max_steps=10, use_weights=False, scatter_first=0, time_kernels=False, walk=-1, tail=-1, counting=-1):
+        super().__init__(int(max_steps), int(bool(use_weights)), int(scatter_first), int(bool(time_kernels)), int(walk), int(tail), int(counting))
+
+
 class DaqTables(Structure):
     """chroma_daq_tables"""
     _fields_ = [('d_time_cdf_x', c_void_p), ('d_time_cdf_y', c_void_p), ('time_cdf_len', c_int32),
@@ -133,6 +142,8 @@ SIGNATURES = {
                                    c_int32, c_int32, c_int32, POINTER(PropagateStats), POINTER(c_int32)]),
     'chroma_propagate_hits': (c_int32, [c_void_p, c_void_p, POINTER(PhotonArrays), c_uint64, c_uint32, Rng, c_int32,
                                         c_int32, c_int32, c_int32, POINTER(PropagateStats), POINTER(c_int32), POINTER(HitsRequest)]),
+    'chroma_propagate_opt': (c_int32, [c_void_p, c_void_p, POINTER(PhotonArrays), c_uint64, c_uint32, Rng, POINTER(PropagateOptions),
+                                       POINTER(PropagateStats), POINTER(c_int32), POINTER(HitsRequest)]),
     'chroma_channel_hits': (c_int32, [c_void_p, c_void_p, c_uint64, c_uint32, POINTER(PhotonArrays),
                                       c_void_p, c_void_p]),
     'chroma_daq_reset': (c_int32, [c_void_p, c_float, c_uint32, c_void_p, c_void_p, c_void_p]),

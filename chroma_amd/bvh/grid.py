@@ -147,24 +147,30 @@ def _build_numpy(vertices, triangles, world_coords, target_degree):
     return nodes, bounds
 
 
-def _device_context():
-    """The current chroma_amd.gpu context, or a new one on device 0 when the machine has a GPU; None otherwise."""
+def _device_context(cuda_device=None):
+    """(context, created): the current chroma_amd.gpu context when it sits on the device asked for (``cuda_device`` None: any),
+    else a NEW context on ``cuda_device`` (None: device 0) when the machine has a GPU -- the caller pops a context it had
+    created, as chroma/loader.py:150-152 does with the CUDA context it makes for the build; (None, False) without a GPU."""
     try:
         from chroma_amd.gpu import tools as gtools
-        if gtools._current is not None:
-            return gtools._current
+        cur = gtools._current
+        if cur is not None and (cuda_device is None or int(cuda_device) == int(cur.device_id)):
+            return cur, False
         if gtools.device_count() > 0:
-            return gtools.get_context()
+            return gtools.Context(0 if cuda_device is None else int(cuda_device)), True      # (not pushed: the caller's stays current)
     except Exception:
         pass
-    return None
+    return None, False
 
 
-def make_recursive_grid_bvh(mesh, target_degree=3, verbose=False, backend=None):
-    """BVH of ``mesh`` (chroma/bvh/grid.py:11).  ``backend``: 'device' (HIP kernels on the current context's GPU, as
-    in the reference, where these steps are CUDA kernels), 'native' (the same algorithm on the host cores), 'numpy'
-    (the independent restatement); None = $CHROMA_BVH_BACKEND, else 'device' when a GPU is there and 'native'
-    otherwise.  All three return the same node array bit for bit."""
+def make_recursive_grid_bvh(mesh, target_degree=3, verbose=False, backend=None, cuda_device=None):
+    """BVH of ``mesh`` (chroma/bvh/grid.py:11).  ``backend``: 'device' (HIP kernels, as in the reference, where these steps
+    are CUDA kernels), 'native' (the same algorithm on the host cores), 'numpy' (the independent restatement); None =
+    $CHROMA_BVH_BACKEND, else 'device' when a GPU is there and 'native' otherwise.  All three return the same node array bit
+    for bit.  ``cuda_device``: the GPU a device build runs on (chroma/loader.py:150 builds on ``create_cuda_context(cuda_device)``)
+    -- the current context when it is on that device, else a context made for the build and released afterwards, so loading
+    a geometry leaves no context behind.  A device build that runs out of memory gives the pool back, and if that is not
+    enough the host cores build the same tree."""
     import os
     vertices = np.ascontiguousarray(mesh.vertices, dtype=np.float32)
     triangles = np.ascontiguousarray(mesh.triangles, dtype=np.uint32)
@@ -172,16 +178,34 @@ def make_recursive_grid_bvh(mesh, target_degree=3, verbose=False, backend=None):
         raise ValueError('mesh has too many triangles for 28-bit child indices')
     world_coords = world_coords_for(vertices)
     backend = backend or os.environ.get('CHROMA_BVH_BACKEND') or 'auto'
-    ctx = None
+    ctx, created = None, False
     if backend in ('auto', 'device'):
-        ctx = _device_context()
+        ctx, created = _device_context(cuda_device)
         if ctx is None and backend == 'device':
             raise RuntimeError("backend='device' needs a GPU (chroma_amd.gpu.create_cuda_context)")
         backend = 'native' if ctx is None else 'device'
     if backend in ('native', 'device'):
         from chroma_amd import _lib
-        nodes, bounds = _lib.bvh_build(vertices, triangles, world_coords.world_origin,
-                                       world_coords.world_scale, target_degree, ctx=ctx)
+        try:
+            try:
+                nodes, bounds = _lib.bvh_build(vertices, triangles, world_coords.world_origin,
+                                               world_coords.world_scale, target_degree, ctx=ctx)
+            except _lib.ChromaError as exc:
+                if ctx is None or 'memory' not in str(exc).lower():
+                    raise
+                # the builder's scratch (~60 bytes per triangle) did not fit beside what the device holds: blocks parked in
+                # the pool go back first; then the host cores build the same nodes
+                ctx.pool_trim()
+                try:
+                    nodes, bounds = _lib.bvh_build(vertices, triangles, world_coords.world_origin,
+                                                   world_coords.world_scale, target_degree, ctx=ctx)
+                except _lib.ChromaError:
+                    backend = 'native'
+                    nodes, bounds = _lib.bvh_build(vertices, triangles, world_coords.world_origin,
+                                                   world_coords.world_scale, target_degree, ctx=None)
+        finally:
+            if created:
+                ctx.shutdown()
     elif backend == 'numpy':
         nodes, bounds = _build_numpy(vertices, triangles, world_coords, target_degree)
     else:

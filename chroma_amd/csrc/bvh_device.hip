@@ -48,12 +48,14 @@ const int MAX_CHILD = 15;          // 2^(32-28) - 1, chroma/bvh/grid.py:6
 
 // every device buffer of one build; freed together whatever happens
 struct Arena {
+    chroma_ctx *ctx = nullptr;       // (allocations go through the context: out of memory gives the pool back and tries again)
     std::vector<void *> ptrs;
     ~Arena() { for (void *p : ptrs) if (p) hipFree(p); }
     template <class T> hipError_t get(T **out, size_t count)
     {
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        hipError_t e = ctx ? chroma_internal_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes);
         if (e == hipSuccess) ptrs.push_back(p);
         *out = (T *)p;
         return e;
@@ -238,6 +240,7 @@ int chroma_bvh_build_device(chroma_ctx *ctx, const float *vertices, uint32_t nve
     DEV_TRY(hipSetDevice(chroma_internal_device(ctx)));
     Lap lap(stream);
     Arena arena;
+    arena.ctx = ctx;
     const uint32_t n = ntriangles;
     const float ox = world_origin[0], oy = world_origin[1], oz = world_origin[2], ws = world_scale;
 
@@ -410,6 +413,7 @@ extern "C" int chroma_photons_sort_direction(chroma_ctx *ctx, const chroma_photo
     DEV_TRY(hipSetDevice(chroma_internal_device(ctx)));
     const uint32_t n = (uint32_t)nphotons;
     Arena arena;
+    arena.ctx = ctx;
     uint32_t *d_codes, *d_codes_sorted, *d_ids, *d_order, *d_buf;
     DEV_TRY(arena.get(&d_codes, n)); DEV_TRY(arena.get(&d_codes_sorted, n));
     DEV_TRY(arena.get(&d_ids, n)); DEV_TRY(arena.get(&d_order, n));

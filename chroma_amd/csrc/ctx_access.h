@@ -8,6 +8,9 @@ extern "C" {
 hipStream_t chroma_internal_stream(chroma_ctx *ctx);
 int chroma_internal_device(chroma_ctx *ctx);
 int chroma_internal_set_error(int code, const char *fmt, ...);      // returns `code`
+// hipMalloc for the library's own buffers and scratch: when the device is out of memory, the blocks parked in the pool
+// behind chroma_malloc / chroma_free are given back and the allocation is tried once more (free with hipFree)
+hipError_t chroma_internal_malloc(chroma_ctx *ctx, void **ptr, size_t bytes);
 // copies of any size between host memory (pageable is fine) and the device, through the context's pinned staging ring;
 // both return when the data has arrived
 int chroma_internal_dtoh(chroma_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes);

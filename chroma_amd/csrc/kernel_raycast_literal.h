@@ -1,4 +1,4 @@
-// raycast_literal.h -- the exact walk: chroma/cuda/mesh.h:42-118 for every ray, four lanes per ray.
+// kernel_raycast_literal.h -- k_raycast_literal, the exact walk: chroma/cuda/mesh.h:42-118 for every ray, four lanes per ray.
 //
 // (Included by chroma_hip.hip; needs its StepState, HIT_* codes and the quad DPP helpers.)
 //

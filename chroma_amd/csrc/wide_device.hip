@@ -55,12 +55,14 @@ namespace {
     } while (0)
 
 struct Arena {          // every device buffer of one build; freed together whatever happens
+    chroma_ctx *ctx = nullptr;       // (allocations go through the context: out of memory gives the pool back and tries again)
     std::vector<void *> ptrs;
     ~Arena() { for (void *p : ptrs) if (p) hipFree(p); }
     template <class T> hipError_t get(T **out, size_t count)
     {
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        hipError_t e = ctx ? chroma_internal_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes);
         if (e == hipSuccess) ptrs.push_back(p);
         *out = (T *)p;
         return e;
@@ -772,6 +774,7 @@ int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nn
     struct Guard { WideTree *t; ~Guard() { delete t; } } guard{t};
     if (nnodes >= 0xFFFFFFFFull) return chroma_internal_set_error(CHROMA_ERR_INVALID, "chroma_wide_build_device: too many nodes");
     Arena arena;
+    arena.ctx = ctx;
     uint4 *d_nodes; uint32_t *d_leaf_node, *d_flag, *d_rank, *d_counters;
     DEV_TRY(arena.get(&d_nodes, (size_t)nnodes));
     DEV_TRY(arena.get(&d_leaf_node, ntriangles));

@@ -27,8 +27,11 @@ def spherical_spiral(radius, spacing):
         t += dl / sqrt(1 + a ** 2 * sin(t) ** 2)
 
 
-def detector(pmt_radius=14000.0, sphere_radius=14500.0, spiral_step=350.0):
-    pmt = build_8inch_pmt_with_lc()
+def detector(pmt_radius=14000.0, sphere_radius=14500.0, spiral_step=350.0, pmt_profile=None, cone_profile=None):
+    """chroma/demo/__init__.py:32-64.  ``pmt_profile`` / ``cone_profile`` (or $CHROMA_PMT_PROFILE / $CHROMA_CONE_PROFILE): the
+    reference's digitised outlines (chroma/demo/sno_pmt.txt, sno_cone.txt) where they are at hand, instead of the analytic
+    tube of chroma_amd/demo/pmt.py."""
+    pmt = build_8inch_pmt_with_lc(pmt_profile=pmt_profile, cone_profile=cone_profile)
     geo = Detector(water)
     geo.add_solid(Solid(sphere(sphere_radius, nsteps=200), water, water,
                         surface=black_surface, color=0xBBFFFFFF))
@@ -51,18 +54,18 @@ def detector(pmt_radius=14000.0, sphere_radius=14500.0, spiral_step=350.0):
     return geo
 
 
-def tiny():
-    return detector(2000.0, 2500.0, 700.0)
+def tiny(**profiles):
+    return detector(2000.0, 2500.0, 700.0, **profiles)
 
 
-def detector_lite():
+def detector_lite(**profiles):
     """~500 PMTs (BASELINE.md "C2-lite"), for quick turn-around only."""
-    return detector(pmt_radius=3120.0, sphere_radius=3620.0, spiral_step=350.0)
+    return detector(pmt_radius=3120.0, sphere_radius=3620.0, spiral_step=350.0, **profiles)
 
 
-def detector29k():
+def detector29k(**profiles):
     """29 007 PMTs at the demo pitch."""
-    return detector(pmt_radius=23780.0, sphere_radius=24280.0, spiral_step=350.0)
+    return detector(pmt_radius=23780.0, sphere_radius=24280.0, spiral_step=350.0, **profiles)
 
 
 def scintillator_stress():

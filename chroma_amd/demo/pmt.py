@@ -7,10 +7,17 @@ bulb -- sampled with as many points as the digitised SNO tube drawing the refere
 ships (55 per half outline, 16 on the cone), so a PMT has the same triangle count
 (5 856 with its collector) and the demo detectors have the sizes quoted in BASELINE.md.
 Files in the reference's profile format still load through chroma_amd.pmt.build_pmt.
+
+A site that HAS the reference's digitised drawings (chroma/demo/sno_pmt.txt and sno_cone.txt, which this repository does
+not ship) can run the demo detectors -- C1, C2, C3 -- on them: point $CHROMA_PMT_PROFILE / $CHROMA_CONE_PROFILE at the two
+files, or pass ``pmt_profile=`` / ``cone_profile=`` to the builders (chroma_amd.demo.tiny / detector / detector29k forward
+them).  The files go through build_pmt / build_light_collector_from_file exactly as in chroma/demo/pmt.py:7-20.
 """
+import os
+
 import numpy as np
 
-from chroma_amd.pmt import build_pmt_from_profile, build_light_collector_from_profile
+from chroma_amd.pmt import build_pmt, build_light_collector_from_file, build_pmt_from_profile, build_light_collector_from_profile
 from chroma_amd.demo.optics import water, glass, vacuum, shiny_surface, r7081hqe_photocathode
 
 NECK_RADIUS = 40.0        # mm
@@ -44,15 +51,24 @@ def cone_outline():
     return np.column_stack([-r, y])
 
 
-def build_8inch_pmt(outer_material=water, nsteps=24):
-    return build_pmt_from_profile(pmt_outline(), 3.0,   # 3 mm of glass
-                                  outer_material=outer_material, glass=glass, vacuum=vacuum,
-                                  photocathode_surface=r7081hqe_photocathode,
-                                  back_surface=shiny_surface, nsteps=nsteps)
+def build_8inch_pmt(outer_material=water, nsteps=24, pmt_profile=None):
+    """chroma/demo/pmt.py:7-13.  ``pmt_profile`` (or $CHROMA_PMT_PROFILE): a glass outline FILE in the reference's format
+    (its sno_pmt.txt) instead of the analytic tube."""
+    pmt_profile = pmt_profile or os.environ.get('CHROMA_PMT_PROFILE')
+    kw = dict(outer_material=outer_material, glass=glass, vacuum=vacuum, photocathode_surface=r7081hqe_photocathode,
+              back_surface=shiny_surface, nsteps=nsteps)
+    if pmt_profile:
+        return build_pmt(pmt_profile, 3.0, **kw)               # 3 mm of glass
+    return build_pmt_from_profile(pmt_outline(), 3.0, **kw)
 
 
-def build_8inch_pmt_with_lc(outer_material=water, nsteps=24):
-    pmt = build_8inch_pmt(outer_material, nsteps)
-    lc = build_light_collector_from_profile(cone_outline(), outer_material=outer_material,
-                                            surface=shiny_surface, nsteps=nsteps)
+def build_8inch_pmt_with_lc(outer_material=water, nsteps=24, pmt_profile=None, cone_profile=None):
+    """chroma/demo/pmt.py:15-20.  ``cone_profile`` (or $CHROMA_CONE_PROFILE): the light collector's profile FILE (the
+    reference's sno_cone.txt) instead of the analytic cone."""
+    pmt = build_8inch_pmt(outer_material, nsteps, pmt_profile=pmt_profile)
+    cone_profile = cone_profile or os.environ.get('CHROMA_CONE_PROFILE')
+    if cone_profile:
+        lc = build_light_collector_from_file(cone_profile, outer_material=outer_material, surface=shiny_surface, nsteps=nsteps)
+    else:
+        lc = build_light_collector_from_profile(cone_outline(), outer_material=outer_material, surface=shiny_surface, nsteps=nsteps)
     return pmt + lc

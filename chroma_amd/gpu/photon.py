@@ -124,7 +124,7 @@ class GPUPhotons(object):
 
     @profile_if_possible
     def propagate(self, gpu_geometry, rng_states, nthreads_per_block=64, max_blocks=1024, max_steps=10,
-                  use_weights=False, scatter_first=0, track=False, stats=None, time_kernels=False, exact=False):
+                  use_weights=False, scatter_first=0, track=False, stats=None, time_kernels=False, exact=False, counting=None):
         """Propagate to termination or ``max_steps``, whichever comes first.  May be called
         repeatedly to single-step.  With ``track=True`` returns (step_photon_ids, step_photons)
         like the reference (chroma/gpu/photon.py:218-238,258-259).
@@ -133,15 +133,9 @@ class GPUPhotons(object):
         walk 'literal') for this call -- the reference's triangle on EVERY ray, including the numerically erratic
         Moeller-Trumbore hits the default nearest-first walk does not reproduce (~2e-6 of rays aimed exactly at mesh
         features, none in 2.4e8 random photons; include/chroma_hip.h at chroma_set_walk), at several times the cost.
-        (``track=True`` always runs the literal loop: one lane per photon, chroma_propagate_step.)"""
-        if exact and self.ctx.walk != 'literal':
-            previous = self.ctx.walk
-            self.ctx.set_walk('literal')
-            try:
-                return self.propagate(gpu_geometry, rng_states, nthreads_per_block, max_blocks, max_steps, use_weights,
-                                      scatter_first, track, stats, time_kernels)
-            finally:
-                self.ctx.set_walk(previous)
+        (``track=True`` always runs the literal loop: one lane per photon, chroma_propagate_step.)
+        ``counting``: whether the kernels count node visits and triangle tests for ``stats`` (None: the context's setting).
+        Both travel with the call (chroma_propagate_options): they do not change the context, so two threads may use one."""
         nphotons = self.pos.size
         lib, ctx = self.ctx._lib, self.ctx
         rng = self._rng(rng_states)
@@ -149,10 +143,11 @@ class GPUPhotons(object):
         if not track:
             st = _lib.PropagateStats()
             aborted = ctypes.c_int32(0)
-            _lib.check(lib.chroma_propagate(ctx.handle, gpu_geometry.handle, ctypes.byref(s), nphotons,
-                                            self.ncopies, rng, int(max_steps), int(bool(use_weights)),
-                                            int(scatter_first), int(bool(time_kernels)), ctypes.byref(st),
-                                            ctypes.byref(aborted)))
+            # (what the call does travels WITH the call -- chroma_propagate_options -- not as a setting of the context)
+            opt = _lib.PropagateOptions(max_steps, use_weights, scatter_first, time_kernels, walk=ctx.WALKS['literal'] if exact else -1,
+                                        counting=-1 if counting is None else int(bool(counting)))
+            _lib.check(lib.chroma_propagate_opt(ctx.handle, gpu_geometry.handle, ctypes.byref(s), nphotons, self.ncopies, rng,
+                                                ctypes.byref(opt), ctypes.byref(st), ctypes.byref(aborted), None))
             if stats is not None:
                 for k, v in st.as_dict().items():
                     stats[k] = stats.get(k, 0) + v
@@ -200,14 +195,6 @@ class GPUPhotons(object):
         hit count and earliest time into them.  Returns what ``get_flat_hits`` would return after ``propagate`` (the same set of photons;
         their order is unspecified, as in the reference).  ``capacity``: room for that many flat hits (default: a quarter of the photons, at least
         65 536); should more be detected, the full set is fetched with ``get_flat_hits`` afterwards."""
-        if exact and self.ctx.walk != 'literal':
-            previous = self.ctx.walk
-            self.ctx.set_walk('literal')
-            try:
-                return self.propagate_hits(gpu_detector, rng_states, max_steps, use_weights, scatter_first, target_flag, capacity,
-                                           channel_arrays, stats, time_kernels)
-            finally:
-                self.ctx.set_walk(previous)
         nphotons = self.pos.size
         lib, ctx = self.ctx._lib, self.ctx
         if capacity is None:
@@ -227,9 +214,9 @@ class GPUPhotons(object):
             req.d_earliest_time_bits = channel_arrays[1].ptr if channel_arrays[1] is not None else None
         st = _lib.PropagateStats()
         aborted = ctypes.c_int32(0)
-        _lib.check(lib.chroma_propagate_hits(ctx.handle, gpu_detector.handle, ctypes.byref(s), nphotons, self.ncopies,
-                                             self._rng(rng_states), int(max_steps), int(bool(use_weights)), int(scatter_first),
-                                             int(bool(time_kernels)), ctypes.byref(st), ctypes.byref(aborted), ctypes.byref(req)))
+        opt = _lib.PropagateOptions(max_steps, use_weights, scatter_first, time_kernels, walk=ctx.WALKS['literal'] if exact else -1)
+        _lib.check(lib.chroma_propagate_opt(ctx.handle, gpu_detector.handle, ctypes.byref(s), nphotons, self.ncopies,
+                                            self._rng(rng_states), ctypes.byref(opt), ctypes.byref(st), ctypes.byref(aborted), ctypes.byref(req)))
         if stats is not None:
             for k, v in st.as_dict().items():
                 stats[k] = stats.get(k, 0) + v

@@ -73,6 +73,14 @@ class Context(object):
     def detach(self):
         self.pop()
 
+    def shutdown(self):
+        """pop() and give the device side of this context back (chroma_shutdown: stream, pool, staging buffers).  The
+        context cannot be used afterwards; device arrays made on it must be gone by then."""
+        if self.handle is not None and self.handle.value:
+            self.pop()
+            _lib.check(self._lib.chroma_shutdown(self.handle))
+            self.handle = ctypes.c_void_p()
+
     def mem_get_info(self):
         free, total = ctypes.c_size_t(), ctypes.c_size_t()
         _lib.check(self._lib.chroma_mem_info(self.handle, ctypes.byref(free), ctypes.byref(total)))

@@ -1,7 +1,9 @@
 """Geometry loading helpers (the part of chroma/loader.py the propagate path needs).
 
-``load_bvh`` (chroma/loader.py:131-160) in the reference needs a CUDA context because its
-BVH builder runs on the GPU; here the builder is host code, so no device is touched.
+``load_bvh`` (chroma/loader.py:131-160) in the reference makes a CUDA context on ``cuda_device`` because its BVH
+builder runs on the GPU, and pops it afterwards.  Same here: the BVH is built on the device when there is one -- on the
+current context if that sits on ``cuda_device``, else on a context made for the build and released again -- and on the
+host cores otherwise (same nodes bit for bit: chroma_amd/bvh/grid.py).
 BVHs are cached as .npz files (chroma_amd/cache.py) when a ``cache_dir`` is given; unlike the
 reference the cache is OFF by default, because a build takes seconds.
 ``load_geometry_from_string`` resolves the "@module.function" form of chroma/loader.py:90-112.
@@ -32,7 +34,7 @@ def load_bvh(geometry, bvh_name="default", auto_build_bvh=True, read_bvh_cache=T
     if not auto_build_bvh:
         raise Exception('BVH "%s" not found in cache and auto_build_bvh is off' % bvh_name)
     logger.info('Building new BVH using recursive grid algorithm.')
-    bvh = make_recursive_grid_bvh(geometry.mesh, target_degree=target_degree)
+    bvh = make_recursive_grid_bvh(geometry.mesh, target_degree=target_degree, cuda_device=cuda_device)
     if cache is not None and update_bvh_cache:
         logger.info('Saving BVH (%s:%s) to cache.' % (mesh_hash, bvh_name))
         cache.save_bvh(bvh, mesh_hash, bvh_name)
@@ -60,7 +62,7 @@ def create_geometry_from_obj(obj, bvh_name="default", auto_build_bvh=True, read_
     geometry.flatten()
     if geometry.bvh is None:
         geometry.bvh = load_bvh(geometry, bvh_name=bvh_name, auto_build_bvh=auto_build_bvh, read_bvh_cache=read_bvh_cache,
-                                update_bvh_cache=update_bvh_cache, cache_dir=cache_dir)
+                                update_bvh_cache=update_bvh_cache, cache_dir=cache_dir, cuda_device=cuda_device)
     return geometry
 
 
@@ -70,11 +72,11 @@ def load_geometry_from_string(geometry_str, auto_build_bvh=True, read_bvh_cache=
     ``"file.stl[.bz2][:bvh]"`` (a mesh on disk, vacuum inside and out), ``"@module.name[:bvh]"`` (a Geometry, Solid or Mesh, or a
     function that returns one when called without arguments; the current directory is importable too),
     ``"name[:bvh]"`` (a geometry saved in the cache under that name) and ``""`` (the cache's default geometry).
-    ``cuda_device`` is accepted for compatibility: the BVH is built on the host."""
+    ``cuda_device``: the GPU the BVH is built on (load_bvh)."""
     geometry_id, _, bvh_name = geometry_str.partition(':')
     bvh_name = bvh_name or 'default'
     kw = dict(bvh_name=bvh_name, auto_build_bvh=auto_build_bvh, read_bvh_cache=read_bvh_cache,
-              update_bvh_cache=update_bvh_cache, cache_dir=cache_dir)
+              update_bvh_cache=update_bvh_cache, cache_dir=cache_dir, cuda_device=cuda_device)
     if geometry_id.startswith('@'):
         module_name, _, function_name = geometry_id[1:].rpartition('.')
         saved = list(sys.path)

@@ -138,7 +138,12 @@ class Simulation(object):
     def simulate(self, iterable, keep_photons_beg=False, keep_photons_end=False, keep_hits=True,
                  keep_flat_hits=True, run_daq=False, max_steps=1000, photons_per_batch=1000000, evid_start=0):
         """Simulate Photons objects (or Events that already carry ``photons_beg``); events are
-        batched until ``photons_per_batch`` photons are collected (chroma/sim.py:141-186)."""
+        batched until ``photons_per_batch`` photons are collected (chroma/sim.py:141-186).
+
+        With ``Simulation(prefetch=True)`` (the default) the NEXT batch is taken from ``iterable`` and uploaded by a second
+        thread while the current one propagates: the iterable is consumed one batch ahead of the events this generator
+        yields.  An iterable whose items share buffers, or depend on results already yielded, needs ``prefetch=False``;
+        ``keep_photons_beg=True`` turns the read-ahead off by itself (the reference's loop is lazy, chroma/sim.py:141-186)."""
         if isinstance(iterable, event.Photons):
             first, iterable = iterable, [iterable]
         else:
@@ -171,7 +176,10 @@ class Simulation(object):
             if batch:
                 yield batch
 
-        if not self.prefetch or self.photon_tracking:
+        # (read-ahead contract: with prefetch the iterable is pulled one batch ahead of the events being yielded, and `evidx` is
+        #  written into the photons of that next batch early; a generator that reuses its buffers, or a caller who wants
+        #  `photons_beg` back untouched, gets the reference's lazy loop instead)
+        if not self.prefetch or self.photon_tracking or keep_photons_beg:
             for batch in batches():
                 yield from self._simulate_batch(batch, **kwargs)
             return

@@ -306,6 +306,24 @@ int chroma_propagate_hits(chroma_ctx *ctx, chroma_geometry *geom, const chroma_p
                           int32_t time_kernels, chroma_propagate_stats *stats, int32_t *aborted,
                           chroma_hits_request *hits);
 
+/* The general form of the two calls above: what a call does is an ARGUMENT, not a setting of the context -- which walk the ray
+ * cast takes (GPUPhotons.propagate(exact=True) passes CHROMA_WALK_LITERAL here), how the tail runs, whether the kernels count
+ * their work.  A field of -1 takes the context's setting (chroma_set_walk / chroma_set_tail / chroma_set_counting or the CHROMA_*
+ * environment) as it is when the call starts; nothing a concurrent call or setter does changes a call under way.  Calls on one
+ * context run one at a time (the context's queues and working sets are its own): two threads may share a handle.
+ * `hits` may be NULL (then this is chroma_propagate).  Zero the structure, then set what you need: reserved fields must be 0. */
+typedef struct chroma_propagate_options {
+    int32_t max_steps, use_weights, scatter_first, time_kernels;      /* as the arguments of chroma_propagate */
+    int32_t walk;          /* CHROMA_WALK_* or -1 */
+    int32_t tail;          /* CHROMA_TAIL_* or -1 */
+    int32_t counting;      /* 0, 1 or -1 */
+    int32_t reserved[5];
+} chroma_propagate_options;
+int chroma_propagate_opt(chroma_ctx *ctx, chroma_geometry *geom, const chroma_photon_arrays *photons,
+                         uint64_t nphotons, uint32_t ncopies, chroma_rng rng,
+                         const chroma_propagate_options *options,
+                         chroma_propagate_stats *stats, int32_t *aborted, chroma_hits_request *hits);
+
 /* Per-channel reduction of detected photons: hit count and earliest hit time
  * (float bits, valid for t >= 0 as in chroma/cuda/daq.cu:5-20).  The arrays
  * (length nchannels, device) are ACCUMULATED into: zero / 0x7f800000-fill them first.

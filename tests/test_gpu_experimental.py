@@ -1,22 +1,32 @@
-"""k_raycast_packet: the first step of a propagate call with 64 rays per wavefront walking the wide tree as one packet.
+"""The experiments that did not pay and therefore live OUTSIDE the product library (chroma_amd/csrc/experimental/, built into
+build_variants/libchroma_hip_experimental.so by `make variants`): the packet ray cast and the engine-side direction sort.
+They stay parity-green -- tested here through the variant library -- and the product library refuses to switch them on.
+
+k_raycast_packet: the first step of a propagate call with 64 rays per wavefront walking the wide tree as one packet.
 Whatever the rays look like, every photon must come out as the default (quad) walk and the oracle give it, bit for bit;
 only the speed depends on coherence (and it is not better than the default walk's: profiles/r03/ab_packet_first_step.txt
 -- the kernel is an opt-in, off by default).  'auto' must pick the packet kernel for a direction-sorted bomb and leave an
 unsorted one to the quad walk."""
+import os
+
 import numpy as np
 import pytest
 
 from chroma_amd import event
-from conftest import bomb
+from conftest import ROOT, bomb
 from test_gpu_parity import assert_bit_exact, _edge_photons
 
 pytestmark = pytest.mark.gpu
+
+VARIANT = os.path.join(ROOT, 'build_variants', 'libchroma_hip_experimental.so')
 
 
 @pytest.fixture(scope='module')
 def gpu():
     from chroma_amd import gpu as g
-    ctx = g.create_cuda_context(0)
+    if not os.path.exists(VARIANT):
+        pytest.fail('%s is not built: run `make -C chroma_amd/csrc variants` (build() does)' % VARIANT)
+    ctx = g.create_cuda_context(0, library=VARIANT)
     yield g
     ctx.set_packet('off')
     ctx.pop()
@@ -101,3 +111,58 @@ def test_packet_walk_on_awkward_photons(gpu, oracle_mod, tiny_geometry):
         ctx.set_packet('off')
     assert_bit_exact(gp.get(), two, 'second call: rays starting on their last hit')
     assert np.array_equal(gp.rng_counters.get(), ctr2)
+
+
+def test_a_large_unsorted_bomb_is_taken_up_in_direction_order_with_the_same_results(gpu, oracle_mod, tiny_geometry):
+    """chroma_set_autosort: a call of >= 2^21 photons from one origin in generation order is ordered by direction cell
+    on the device (stats['reordered']); every photon ends exactly as with the photons taken as they come, and as the
+    oracle says; a direction-sorted bomb and photons from many origins are left alone."""
+    import numpy as np
+    n = (1 << 21) + 12345
+    ph = oracle_mod.generate_bomb(n, seed=99)
+    gg = gpu.GPUDetector(tiny_geometry)
+    ctx = gpu.get_context()
+    results = {}
+    for mode in ('off', 'auto', 'on'):
+        ctx.set_autosort(mode)
+        gp = gpu.GPUPhotons(ph)
+        stats = {}
+        gp.propagate(gg, gpu.get_rng_states(64 * 1024, seed=5), max_steps=100, stats=stats)
+        results[mode] = (gp.get(), gp.rng_counters.get(), stats.get('reordered', 0))
+    assert results['off'][2] == 0 and results['auto'][2] == n and results['on'][2] == n
+    ctx.set_autosort('auto')
+    for mode in ('auto', 'on'):
+        for field in ('pos', 'dir', 'pol', 'wavelengths', 't', 'flags', 'last_hit_triangles', 'weights'):
+            assert np.array_equal(getattr(results[mode][0], field).view(np.uint32), getattr(results['off'][0], field).view(np.uint32)), (mode, field)
+        assert np.array_equal(results[mode][1], results['off'][1]), mode
+    # against the oracle (the whole call: the launch policy, and with it the arithmetic, depends on how many photons live)
+    from chroma_amd.gpu.geometry import pack_geometry
+    want, counters, _ = oracle_mod.propagate(pack_geometry(tiny_geometry), ph, seed=5, max_steps=100, nthreads=8)
+    assert_bit_exact(results['auto'][0], want, 'autosort')
+    assert np.array_equal(results['auto'][1], counters)
+    # already sorted: left alone; many origins: left alone
+    gp = gpu.GPUPhotons(ph)
+    gp.sort_by_direction()
+    stats = {}
+    gp.propagate(gg, gpu.get_rng_states(64 * 1024, seed=5), max_steps=5, stats=stats)
+    assert stats.get('reordered', 0) == 0
+    moved = oracle_mod.generate_bomb(n, seed=100)
+    moved.pos[:] = np.random.default_rng(1).uniform(-100.0, 100.0, size=moved.pos.shape).astype(np.float32)
+    gp = gpu.GPUPhotons(moved)
+    stats = {}
+    gp.propagate(gg, gpu.get_rng_states(64 * 1024, seed=5), max_steps=5, stats=stats)
+    assert stats.get('reordered', 0) == 0
+    ctx.set_autosort('off')
+
+
+def test_the_product_library_does_not_carry_the_experiments():
+    from chroma_amd import gpu as g
+    from chroma_amd._lib import ChromaError
+    ctx = g.create_cuda_context(0)
+    try:
+        for switch in (ctx.set_packet, ctx.set_autosort):
+            switch('off')
+            with pytest.raises(ChromaError, match='experiment'):
+                switch('on')
+    finally:
+        ctx.pop()

@@ -113,3 +113,42 @@ def test_through_the_spill_area(oracle_mod, tiny_geometry):
         assert stats['stack_spills'] > 1000, stats
     finally:
         ctx.pop()
+
+
+def test_two_threads_on_one_handle_one_exact_one_default(gpu, oracle_mod, tiny_geometry):
+    """What a call does travels with the call (chroma_propagate_options), not as a setting of the context: two threads
+    sharing one context -- one asking for the exact walk, one for the default -- each get the oracle's photons, and the
+    counts say each got the walk it asked for (the exact walk makes the oracle's very tests, the default walk fewer
+    triangle tests over a different tree)."""
+    import threading
+    from chroma_amd.gpu.geometry import pack_geometry
+    gg = gpu.GPUDetector(tiny_geometry)
+    packed = pack_geometry(tiny_geometry)
+    jobs = {'exact': (bomb(60000, 31, wavelength=400.0, wavelength_hi=800.0), True), 'default': (bomb(50000, 32), False)}
+    want = {k: oracle_mod.propagate(packed, ph, seed=77, max_steps=30, nthreads=8) for k, (ph, _) in jobs.items()}
+    failures = []
+
+    def work(name):
+        try:
+            ph, exact = jobs[name]
+            for rep in range(4):
+                gp = gpu.GPUPhotons(ph)
+                stats = {}
+                gp.propagate(gg, gpu.get_rng_states(64, seed=77), max_steps=30, exact=exact, counting=True, stats=stats)
+                end, counters, ostats = want[name]
+                assert_bit_exact(gp.get(), end, '%s thread, call %d' % (name, rep))
+                assert np.array_equal(gp.rng_counters.get(), counters)
+                if exact:
+                    assert stats['nodes_visited'] == ostats['nodes_visited'] and stats['triangles_tested'] == ostats['triangles_tested']
+                else:
+                    assert stats['nodes_visited'] != ostats['nodes_visited'] and 0 < stats['triangles_tested'] < ostats['triangles_tested']
+        except BaseException as exc:      # noqa: B902 (reported by the main thread)
+            failures.append((name, exc))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures
+    assert gpu.get_context().walk == 'quad'

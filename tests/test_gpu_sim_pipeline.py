@@ -82,45 +82,3 @@ def test_simulation_with_prefetch_equals_simulation_without(gpu, tiny_geometry, 
         assert len(hitsa) == len(hitsb) > 0
         oa, ob = np.lexsort((hitsa.t, hitsa.channel)), np.lexsort((hitsb.t, hitsb.channel))
         assert np.array_equal(hitsa.channel[oa], hitsb.channel[ob]) and np.array_equal(hitsa.t[oa].view(np.uint32), hitsb.t[ob].view(np.uint32))
-
-
-def test_a_large_unsorted_bomb_is_taken_up_in_direction_order_with_the_same_results(gpu, oracle_mod, tiny_geometry):
-    """chroma_set_autosort: a call of >= 2^21 photons from one origin in generation order is ordered by direction cell
-    on the device (stats['reordered']); every photon ends exactly as with the photons taken as they come, and as the
-    oracle says; a direction-sorted bomb and photons from many origins are left alone."""
-    import numpy as np
-    n = (1 << 21) + 12345
-    ph = oracle_mod.generate_bomb(n, seed=99)
-    gg = gpu.GPUDetector(tiny_geometry)
-    ctx = gpu.get_context()
-    results = {}
-    for mode in ('off', 'auto', 'on'):
-        ctx.set_autosort(mode)
-        gp = gpu.GPUPhotons(ph)
-        stats = {}
-        gp.propagate(gg, gpu.get_rng_states(64 * 1024, seed=5), max_steps=100, stats=stats)
-        results[mode] = (gp.get(), gp.rng_counters.get(), stats.get('reordered', 0))
-    assert results['off'][2] == 0 and results['auto'][2] == n and results['on'][2] == n
-    ctx.set_autosort('auto')
-    for mode in ('auto', 'on'):
-        for field in ('pos', 'dir', 'pol', 'wavelengths', 't', 'flags', 'last_hit_triangles', 'weights'):
-            assert np.array_equal(getattr(results[mode][0], field).view(np.uint32), getattr(results['off'][0], field).view(np.uint32)), (mode, field)
-        assert np.array_equal(results[mode][1], results['off'][1]), mode
-    # against the oracle (the whole call: the launch policy, and with it the arithmetic, depends on how many photons live)
-    from chroma_amd.gpu.geometry import pack_geometry
-    want, counters, _ = oracle_mod.propagate(pack_geometry(tiny_geometry), ph, seed=5, max_steps=100, nthreads=8)
-    assert_bit_exact(results['auto'][0], want, 'autosort')
-    assert np.array_equal(results['auto'][1], counters)
-    # already sorted: left alone; many origins: left alone
-    gp = gpu.GPUPhotons(ph)
-    gp.sort_by_direction()
-    stats = {}
-    gp.propagate(gg, gpu.get_rng_states(64 * 1024, seed=5), max_steps=5, stats=stats)
-    assert stats.get('reordered', 0) == 0
-    moved = oracle_mod.generate_bomb(n, seed=100)
-    moved.pos[:] = np.random.default_rng(1).uniform(-100.0, 100.0, size=moved.pos.shape).astype(np.float32)
-    gp = gpu.GPUPhotons(moved)
-    stats = {}
-    gp.propagate(gg, gpu.get_rng_states(64 * 1024, seed=5), max_steps=5, stats=stats)
-    assert stats.get('reordered', 0) == 0
-    ctx.set_autosort('off')

@@ -51,7 +51,10 @@ def test_streaming_kernels_run_at_full_occupancy(isa_table):
 
 
 def test_every_kernel_of_the_path_is_in_the_table(isa_table):
-    for name in ('k_physics<false>', 'k_physics<true>', 'k_tail_coop<false>', 'k_propagate<24, false>', 'k_raycast_retry<false, false>', 'k_raycast_retry<false, true>', 'k_raycast_wide<false>',
+    # the exact walk: full occupancy, its state in registers
+    k = isa_table['k_raycast_literal<false>']
+    assert k['scratch'] == 0 and k['waves'] == 8 and k['vgpr'] <= 64 and k['lds'] == 16 * 33 * 4, k
+    for name in ('k_physics<false>', 'k_physics<true>', 'k_tail_coop<false>', 'k_finalize_hits', 'k_propagate<24, false>', 'k_raycast_retry<false, false>', 'k_raycast_retry<false, true>', 'k_raycast_wide<false>',
                  'k_raycast_persistent<false>', 'k_distance_to_mesh<24, false>', 'k_copy_hits', 'k_daq_reset', 'k_daq_convert'):
         assert name in isa_table, name
     assert isa_table['k_physics<true>']['waves'] >= 4
@@ -61,4 +64,6 @@ def test_every_kernel_of_the_path_is_in_the_table(isa_table):
     # round of ~4 200, one store/load pair of them back to back -- which the measured numbers of round 3 include.
     k = isa_table['k_physics<false>']
     assert k['scratch'] <= 24 and k['waves'] >= 5 and k['vgpr'] <= 96 and k['code'] < 40000, k
-    assert isa_table['k_physics<true>']['scratch'] <= 160
+    # (the all-models build: 128 VGPRs at 4 waves and a spill area -- 136 bytes in round 3, 176 with the final-record store of
+    #  chroma_propagate_hits beside the array stores)
+    assert isa_table['k_physics<true>']['scratch'] <= 192

@@ -16,9 +16,11 @@ for f in glob.glob(os.path.join(d, 'pass*', '**', '*counter_collection.csv'), re
         k = 'k_raycast_quad<false>' if 'k_raycast_quad<false>' in name else 'k_physics' if 'k_physics' in name else None
         if k:
             tot[k][r['Counter_Name']] += float(r['Counter_Value'])
-h = hashlib.sha256()
-for name in ('chroma_amd/csrc/chroma_hip.hip', 'chroma_amd/csrc/propagate_device.h', 'chroma_amd/csrc/device_common.h', 'include/chroma_math.h'):
-    h.update(open(os.path.join(root, name), 'rb').read())
+sys.path.insert(0, root)
+from bench import kernel_source_hash      # (the one definition of what identifies a kernel build)
+class _H(object):
+    def hexdigest(self): return kernel_source_hash()
+h = _H()
 path = os.path.join(root, 'profiles', 'pmc_traffic.json')
 out = json.load(open(path)) if os.path.exists(path) else {}
 for k, suffix in (('k_raycast_quad<false>', ':sq'), ('k_physics', ':physics:sq')):

@@ -1,3 +1,4 @@
+import sys
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of the bench command into profiles/pmc_traffic.json.
 
 HBM bytes = 2 * FETCH_SIZE(KB) * 1024 + WRITE_SIZE(KB) * 1024.  The factor 2 on FETCH_SIZE is the gfx950
@@ -24,9 +25,11 @@ f, nf = total(fetch_dir, 'FETCH_SIZE', kernel)
 w, nw = total(write_dir, 'WRITE_SIZE', kernel)
 import datetime, hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-h = hashlib.sha256()
-for name in ('chroma_amd/csrc/chroma_hip.hip', 'chroma_amd/csrc/propagate_device.h', 'chroma_amd/csrc/device_common.h', 'include/chroma_math.h'):
-    h.update(open(os.path.join(root, name), 'rb').read())
+sys.path.insert(0, root)
+from bench import kernel_source_hash      # (the one definition of what identifies a kernel build)
+class _H(object):
+    def hexdigest(self): return kernel_source_hash()
+h = _H()
 out[key] = {'kernel': kernel, 'launches': nf, 'fetch_size_kb_sum': f, 'write_size_kb_sum': w,
             'source_hash': h.hexdigest()[:12], 'date': datetime.date.today().isoformat(),
             'hbm_bytes_per_launch': (2.0 * f + w) * 1024.0 / max(nf, 1),
