@@ -48,21 +48,23 @@ const int MAX_CHILD = 15;          // 2^(32-28) - 1, chroma/bvh/grid.py:6
 
 // every device buffer of one build; freed together whatever happens
 struct Arena {
-    chroma_ctx *ctx = nullptr;       // (allocations go through the context: out of memory gives the pool back and tries again)
+    chroma_ctx *ctx = nullptr;       // (blocks come from and go back to the context's pool -- chroma_malloc / chroma_free: a repeated call
+                                     //  allocates nothing, and out of memory gives parked blocks back and tries again)
     std::vector<void *> ptrs;
-    ~Arena() { for (void *p : ptrs) if (p) hipFree(p); }
+    void drop(void *p) { if (ctx) chroma_free(ctx, p); else hipFree(p); }
+    ~Arena() { for (void *p : ptrs) if (p) drop(p); }
     template <class T> hipError_t get(T **out, size_t count)
     {
         void *p = nullptr;
         const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-        hipError_t e = ctx ? chroma_internal_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes);
+        hipError_t e = ctx ? (chroma_malloc(ctx, bytes, &p) == CHROMA_OK ? hipSuccess : hipErrorOutOfMemory) : hipMalloc(&p, bytes);
         if (e == hipSuccess) ptrs.push_back(p);
         *out = (T *)p;
         return e;
     }
     void release(void *p)
     {
-        for (auto &q : ptrs) if (q == p) { hipFree(q); q = nullptr; }
+        for (auto &q : ptrs) if (q == p) { drop(q); q = nullptr; }
     }
 };
 
@@ -487,5 +489,21 @@ extern "C" int chroma_internal_direction_order(chroma_ctx *ctx, const float *d_d
     chroma_free(ctx, codes); chroma_free(ctx, sorted); chroma_free(ctx, ids); chroma_free(ctx, tmp);      // (parked behind the stream's work)
     if (rc != CHROMA_OK) return rc;
     if (e != hipSuccess) return chroma_internal_set_error((int)e, "direction order: %s", hipGetErrorString(e));
+    return CHROMA_OK;
+}
+
+// exclusive prefix sums of n words on the context's stream (scratch from the pool): the counting sort of k_load_working_bucketed
+extern "C" int chroma_internal_exclusive_scan(chroma_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t n)
+{
+    hipStream_t stream = chroma_internal_stream(ctx);
+    size_t tmp_bytes = 0;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_in, d_out, (int)n, stream);
+    if (e != hipSuccess) return chroma_internal_set_error((int)e, "exclusive scan: %s", hipGetErrorString(e));
+    void *tmp = nullptr;
+    int rc = chroma_malloc(ctx, std::max<size_t>(tmp_bytes, 4), &tmp);
+    if (rc != CHROMA_OK) return rc;
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_in, d_out, (int)n, stream);
+    chroma_free(ctx, tmp);          // (parked behind the stream's work)
+    if (e != hipSuccess) return chroma_internal_set_error((int)e, "exclusive scan: %s", hipGetErrorString(e));
     return CHROMA_OK;
 }

@@ -55,19 +55,21 @@ namespace {
     } while (0)
 
 struct Arena {          // every device buffer of one build; freed together whatever happens
-    chroma_ctx *ctx = nullptr;       // (allocations go through the context: out of memory gives the pool back and tries again)
+    chroma_ctx *ctx = nullptr;       // (blocks come from and go back to the context's pool -- chroma_malloc / chroma_free: a repeated call
+                                     //  allocates nothing, and out of memory gives parked blocks back and tries again)
     std::vector<void *> ptrs;
-    ~Arena() { for (void *p : ptrs) if (p) hipFree(p); }
+    void drop(void *p) { if (ctx) chroma_free(ctx, p); else hipFree(p); }
+    ~Arena() { for (void *p : ptrs) if (p) drop(p); }
     template <class T> hipError_t get(T **out, size_t count)
     {
         void *p = nullptr;
         const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-        hipError_t e = ctx ? chroma_internal_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes);
+        hipError_t e = ctx ? (chroma_malloc(ctx, bytes, &p) == CHROMA_OK ? hipSuccess : hipErrorOutOfMemory) : hipMalloc(&p, bytes);
         if (e == hipSuccess) ptrs.push_back(p);
         *out = (T *)p;
         return e;
     }
-    void release(void *p) { for (auto &q : ptrs) if (q == p && p) { hipFree(q); q = nullptr; } }
+    void release(void *p) { for (auto &q : ptrs) if (q == p && p) { drop(q); q = nullptr; } }
 };
 
 inline unsigned blocks_for(size_t n, unsigned block = 256) { return (unsigned)((n + block - 1) / block); }

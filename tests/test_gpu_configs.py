@@ -73,11 +73,11 @@ def c5(gpu):
     cfg.close()
 
 
-def propagate_device_bomb(gpu, cfg, n, id_base, wavelength=400.0, max_steps=100, counting=False, walk=None):
+def propagate_device_bomb(gpu, cfg, n, id_base, wavelength=400.0, max_steps=100, counting=False, walk=None, wavelength_hi=0.0):
     """n bomb photons generated on the device with global ids id_base.., propagated with those streams."""
     from chroma_amd import _lib
     ctx = gpu.get_context()
-    gp = gpu.generate_bomb(n, ENGINE_SEED, id_base=id_base, wavelength_lo=wavelength)
+    gp = gpu.generate_bomb(n, ENGINE_SEED, id_base=id_base, wavelength_lo=wavelength, wavelength_hi=wavelength_hi)
     stats = {}
     if walk:
         ctx.set_walk(walk)
@@ -91,19 +91,20 @@ def propagate_device_bomb(gpu, cfg, n, id_base, wavelength=400.0, max_steps=100,
     return gp, stats
 
 
-def oracle_parity(gpu, oracle_mod, cfg, n, what, wavelength=400.0, id_base=0):
+def oracle_parity(gpu, oracle_mod, cfg, n, what, wavelength=400.0, id_base=0, wavelength_hi=0.0, max_steps=100):
     """The engine on a device-made bomb against the oracle on the oracle-made one (the two generators
     must agree as well)."""
-    gp, stats = propagate_device_bomb(gpu, cfg, n, id_base, wavelength=wavelength, counting=True)
+    gp, stats = propagate_device_bomb(gpu, cfg, n, id_base, wavelength=wavelength, counting=True, wavelength_hi=wavelength_hi,
+                                      max_steps=max_steps)
     got = gp.get()
-    ph = oracle_mod.generate_bomb(n, seed=ENGINE_SEED, id_base=id_base, wavelength_lo=wavelength)
-    want, counters, ostats = oracle_mod.propagate(cfg.packed, ph, seed=ENGINE_SEED, photon_id_base=id_base, max_steps=100,
+    ph = oracle_mod.generate_bomb(n, seed=ENGINE_SEED, id_base=id_base, wavelength_lo=wavelength, wavelength_hi=wavelength_hi)
+    want, counters, ostats = oracle_mod.propagate(cfg.packed, ph, seed=ENGINE_SEED, photon_id_base=id_base, max_steps=max_steps,
                                                   nthreads=min(os.cpu_count() or 1, 64))
     assert_bit_exact(got, want, what)
     assert np.array_equal(gp.rng_counters.get(), counters), '%s: draw counters differ' % what
     assert stats['photon_steps'] == ostats['photon_steps']
     assert stats['launches'] == ostats['launches']
-    assert (got.flags & TERMINAL != 0).mean() > 0.999
+    assert (got.flags & TERMINAL != 0).mean() > (0.999 if max_steps >= 100 else 0.98)
     return gp, got, stats, ostats
 
 
@@ -170,6 +171,18 @@ def test_c3_one_million_photons_match_the_oracle(gpu, oracle_mod, c3):
     assert 0.03 < np.count_nonzero(got.flags & event.SURFACE_DETECT) / 1e6 < 0.15
 
 
+def test_c3_the_benchmark_variants_match_the_oracle(gpu, oracle_mod, c3):
+    """The two variants of the measured configuration: wavelengths U(400, 800) nm -- the reference
+    benchmark's own choice, chroma/benchmark.py:81 -- and max_steps = 10, the default of GPUPhotons.propagate and of the
+    reference benchmark (chroma/gpu/photon.py:194), where some photons are still alive when the call ends."""
+    gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c3, 1_000_000, 'C3, 1e6 photons, U(400, 800) nm', wavelength_hi=800.0, id_base=1 << 35)
+    assert 600.0 - 2.0 < float(got.wavelengths.mean()) < 600.0 + 2.0
+    gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c3, 1_000_000, 'C3, 1e6 photons, max_steps 10', max_steps=10, id_base=1 << 36)
+    assert 0 < np.count_nonzero((got.flags & TERMINAL) == 0) < 0.02 * len(got)       # the photons max_steps cut short
+    gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c3, 1_000_000, 'C3, 1e6 photons, U(400, 800) nm, max_steps 10', wavelength_hi=800.0,
+                                           max_steps=10, id_base=1 << 37)
+
+
 def test_c3_full_batch_properties(gpu, c3):
     """1e8 photons (the batch bench.py times): properties + 1e7 of them through the reference walk."""
     stats, nhits = batch_properties(gpu, c3, 100_000_000, id_base=1 << 32)
@@ -191,6 +204,12 @@ def test_c2_one_million_photons_match_the_oracle(gpu, oracle_mod, c2):
     gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c2, 1_000_000, 'C2 demo.detector(), 1e6 photons')
     assert 0.03 < np.count_nonzero(got.flags & event.SURFACE_DETECT) / 1e6 < 0.15
     walks_agree(gpu, c2, 1_000_000, id_base=0, walks=('pair', 'coop', 'wide', 'reference'))
+
+
+def test_c2_the_benchmark_variants_match_the_oracle(gpu, oracle_mod, c2):
+    """U(400, 800) nm (chroma/benchmark.py:81) and max_steps = 10 (chroma/gpu/photon.py:194) on demo.detector()."""
+    oracle_parity(gpu, oracle_mod, c2, 1_000_000, 'C2, 1e6 photons, U(400, 800) nm', wavelength_hi=800.0, id_base=1 << 35)
+    oracle_parity(gpu, oracle_mod, c2, 1_000_000, 'C2, 1e6 photons, U(400, 800) nm, max_steps 10', wavelength_hi=800.0, max_steps=10, id_base=1 << 37)
 
 
 def test_c2_batch_properties(gpu, c2):
