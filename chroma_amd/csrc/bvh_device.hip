@@ -491,19 +491,3 @@ extern "C" int chroma_internal_direction_order(chroma_ctx *ctx, const float *d_d
     if (e != hipSuccess) return chroma_internal_set_error((int)e, "direction order: %s", hipGetErrorString(e));
     return CHROMA_OK;
 }
-
-// exclusive prefix sums of n words on the context's stream (scratch from the pool): the counting sort of k_load_working_bucketed
-extern "C" int chroma_internal_exclusive_scan(chroma_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t n)
-{
-    hipStream_t stream = chroma_internal_stream(ctx);
-    size_t tmp_bytes = 0;
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_in, d_out, (int)n, stream);
-    if (e != hipSuccess) return chroma_internal_set_error((int)e, "exclusive scan: %s", hipGetErrorString(e));
-    void *tmp = nullptr;
-    int rc = chroma_malloc(ctx, std::max<size_t>(tmp_bytes, 4), &tmp);
-    if (rc != CHROMA_OK) return rc;
-    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_in, d_out, (int)n, stream);
-    chroma_free(ctx, tmp);          // (parked behind the stream's work)
-    if (e != hipSuccess) return chroma_internal_set_error((int)e, "exclusive scan: %s", hipGetErrorString(e));
-    return CHROMA_OK;
-}
