@@ -69,7 +69,7 @@ def kernel_source_hash():
 def geometry_source_hash():
     """Identifies what a cached PackedGeometry was built from (CHROMA_BENCH_GEOMETRY_CACHE): the tree topology switch
     and the sources of the host builders and of the demo geometries."""
-    h = hashlib.sha256(os.environ.get('CHROMA_TREE', 'levels').encode())
+    h = hashlib.sha256((os.environ.get('CHROMA_TREE', 'levels') + '/' + os.environ.get('CHROMA_TIGHT_LEAVES', '0')).encode())
     names = [os.path.join('chroma_amd', 'csrc', n) for n in ('wide_build.cpp', 'wide_build.h', 'wide_device.hip', 'bvh_build.cpp', 'mesh_utils.cpp', 'bvh_device.hip')]
     for sub in ('demo', 'bvh'):
         names += sorted(os.path.join('chroma_amd', sub, n) for n in os.listdir(os.path.join(ROOT, 'chroma_amd', sub)) if n.endswith('.py'))

@@ -413,6 +413,7 @@ static uint32_t build_subtree_dp(Prim *prims, size_t first, size_t count, std::v
 // one primitive per triangle that hangs under a reachable leaf, in triangle order (threaded: count, place)
 static void make_prims(const uint32_t *ref, uint32_t ntriangles, const std::vector<uint32_t> &leaf_node, std::vector<Prim> &prims)
 {
+    const int tight = wide_tight_leaves();
     {
         const unsigned nt = hw_threads();
         const size_t chunk = ((size_t)ntriangles + nt - 1) / nt;
@@ -433,7 +434,10 @@ static void make_prims(const uint32_t *ref, uint32_t ntriangles, const std::vect
                     if (leaf_node[t] == 0xFFFFFFFFu) continue;
                     const uint32_t *nd = ref + 4 * (size_t)leaf_node[t];
                     Prim p;
-                    for (int ax = 0; ax < 3; ax++) { p.lo[ax] = (uint16_t)(nd[ax] & 0xFFFFu); p.hi[ax] = (uint16_t)(nd[ax] >> 16); }
+                    for (int ax = 0; ax < 3; ax++) {
+                        const uint32_t w = wide_tight_bound_word(nd[ax], tight);      // (wide_build.h: the reference's padding quantum)
+                        p.lo[ax] = (uint16_t)(w & 0xFFFFu); p.hi[ax] = (uint16_t)(w >> 16);
+                    }
                     p.tri = (uint32_t)t;
                     prims[o++] = p;
                 }
@@ -677,7 +681,7 @@ static int ploc_topology(const uint32_t *ref, size_t leaf_lo, size_t leaf_hi, ui
         const uint32_t *nd = ref + 4 * (leaf_lo + i);
         if ((nd[3] >> NCHILD_SHIFT) != 0 || (nd[3] & CHILD_MASK) >= ntriangles) { err = "wide tree: the last layer of the reference tree is not a layer of leaves"; return -1; }
         PlocCluster c;
-        for (int a = 0; a < 3; a++) { c.lo[a] = (uint16_t)(nd[a] & 0xFFFFu); c.hi[a] = (uint16_t)(nd[a] >> 16); }
+        for (int a = 0; a < 3; a++) { const uint32_t w = wide_tight_bound_word(nd[a], wide_tight_leaves()); c.lo[a] = (uint16_t)(w & 0xFFFFu); c.hi[a] = (uint16_t)(w >> 16); }
         c.node = (uint32_t)i;
         cur[i] = c;
         BinNode &b = d.bin[i];

@@ -1,5 +1,6 @@
 // wide_build.h -- the derived 8-wide traversal tree (see wide_build.cpp).
 #pragma once
+#include <stdlib.h>
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
@@ -53,3 +54,26 @@ int wide_topology_from_env();
 enum { PLOC_RADIUS = 16 };
 
 }  // namespace chroma_host
+
+// ---- the leaf boxes the derived tree is built over ---------------------------------------------------------------------------
+// The reference pads a leaf's LOWER bound by a whole quantum (cuda/bvh.cu:181: ql = trunc((min - origin) / scale), then ql-- when
+// ql > 0) while its upper bound is the plain ceiling (trunc + 1).  A triangle lies inside [trunc(min), trunc(max) + 1] by
+// construction, so the derived tree could do without that quantum: CHROMA_TIGHT_LEAVES=1 moves the lower bounds up by one
+// (a stored 0 stays: it may be an unpadded 0) -- 8.27 -> 7.56 triangle tests per ray step at C3, step -2.2 %
+// (profiles/r04/ab_tight_leaves.txt).  OFF by default: the padding also covers Moeller-Trumbore results of grazing rays that
+// land up to a quantum off their triangle yet inside the reference's leaf box -- hits the reference keeps -- and without it the
+// aimed-ray sweep of C3 finds one ray in 3.6e5 on which the default walk then differs from the reference INSIDE the leaf box.
+// The default walk's deviation class stays "hits outside the reference's own leaf box" (DESIGN.md section 4.1).
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline uint32_t wide_tight_bound_word(uint32_t w, int tight)
+{
+    const uint32_t lo = w & 0xFFFFu;
+    return (tight && lo > 0u && lo + 1u <= (w >> 16)) ? w + 1u : w;
+}
+inline int wide_tight_leaves()
+{
+    const char *e = getenv("CHROMA_TIGHT_LEAVES");
+    return e && e[0] == '1';
+}

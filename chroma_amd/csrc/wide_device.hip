@@ -170,14 +170,15 @@ __global__ void k_prim_flags(const uint32_t *leaf_node, uint32_t ntriangles, uin
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < ntriangles) flag[t] = leaf_node[t] != 0xFFFFFFFFu;
 }
-__global__ void k_make_prims(const uint4 *nodes, const uint32_t *leaf_node, const uint32_t *pos, uint32_t ntriangles, uint4 *prims)
+__global__ void k_make_prims(const uint4 *nodes, const uint32_t *leaf_node, const uint32_t *pos, uint32_t ntriangles, uint4 *prims, int tight)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntriangles) return;
     const uint32_t ln = leaf_node[t];
     if (ln == 0xFFFFFFFFu) return;
     const uint4 nd = nodes[ln];
-    prims[pos[t]] = make_uint4(nd.x, nd.y, nd.z, t);
+    // (wide_build.h: the reference's padding quantum below the triangle is not needed here)
+    prims[pos[t]] = make_uint4(wide_tight_bound_word(nd.x, tight), wide_tight_bound_word(nd.y, tight), wide_tight_bound_word(nd.z, tight), t);
 }
 __global__ void k_last_sum(const uint32_t *a, const uint32_t *b, uint32_t n, uint32_t *out) { if (threadIdx.x == 0 && blockIdx.x == 0) *out = n ? a[n - 1] + b[n - 1] : 0u; }
 
@@ -858,7 +859,7 @@ int chroma_wide_build_device(chroma_ctx *ctx, const uint32_t *nodes, uint64_t nn
     { std::vector<uint32_t>().swap(leaf_node); }
     uint4 *d_prims_a, *d_prims_b;
     DEV_TRY(arena.get(&d_prims_a, np)); DEV_TRY(arena.get(&d_prims_b, np));
-    hipLaunchKernelGGL(k_make_prims, dim3(blocks_for(ntriangles)), dim3(256), 0, stream, d_nodes, d_leaf_node, d_rank, ntriangles, d_prims_a);
+    hipLaunchKernelGGL(k_make_prims, dim3(blocks_for(ntriangles)), dim3(256), 0, stream, d_nodes, d_leaf_node, d_rank, ntriangles, d_prims_a, wide_tight_leaves());
     DEV_TRY(hipGetLastError());
     DEV_TRY(hipStreamSynchronize(stream));
     arena.release(d_nodes); arena.release(d_leaf_node); arena.release(d_flag); arena.release(d_rank); arena.release(d_tmp);

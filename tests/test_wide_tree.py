@@ -68,15 +68,41 @@ def test_every_triangle_is_one_record(built):
             assert recs == list(range(recs[0], recs[0] + len(recs))) if recs else True
 
 
-def test_leaf_boxes_are_the_reference_leaf_boxes(built):
+def test_leaf_boxes_are_the_reference_leaf_boxes(built, monkeypatch):
+    """A leaf entry's box is the reference's leaf box (cuda/bvh.cu:149-203); with CHROMA_TIGHT_LEAVES=1 (an opt-in:
+    wide_build.h) its lower bounds are moved up by the one quantum the reference pads them with -- and it still holds its
+    triangle."""
     g, ref, w = built
+    ent0 = w['wnodes'].reshape(-1, 4)
+    leaf0 = ent0[(ent0[:, 3] & LEAF != 0) & (ent0[:, 3] != EMPTY)]
+    by0 = np.zeros((len(g.mesh.triangles), 3), dtype=np.uint32)
+    by0[w['record_to_tri'][leaf0[:, 3] & 0x7FFFFFFF]] = leaf0[:, :3]
+    ref_leaf0 = ref[(ref[:, 3] >> 28) == 0]
+    want0 = np.zeros_like(by0)
+    want0[ref_leaf0[:, 3] & 0x0FFFFFFF] = ref_leaf0[:, :3]
+    assert np.array_equal(by0, want0)                          # the default: the reference's boxes as they are
+    monkeypatch.setenv('CHROMA_TIGHT_LEAVES', '1')
+    w = dict(_wide(np.ascontiguousarray(g.bvh.nodes), len(g.mesh.triangles), w['topology']), topology=w['topology'])
     ref_leaf = ref[(ref[:, 3] >> 28) == 0]
     by_tri = np.zeros((len(g.mesh.triangles), 3), dtype=np.uint32)
     by_tri[ref_leaf[:, 3] & 0x0FFFFFFF] = ref_leaf[:, :3]
     ent = w['wnodes'].reshape(-1, 4)
     leaf = ent[(ent[:, 3] & LEAF != 0) & (ent[:, 3] != EMPTY)]
     tri = w['record_to_tri'][leaf[:, 3] & 0x7FFFFFFF]
-    assert np.array_equal(leaf[:, :3], by_tri[tri])
+    want = by_tri[tri]
+    lo, hi = want & 0xFFFF, want >> 16
+    tight = np.where((lo > 0) & (lo + 1 <= hi), want + 1, want)
+    if w['topology'] == 'collapse':       # (re-uses the reference tree's own nodes where a range fits a wide node, rebuilds elsewhere)
+        assert ((leaf[:, :3] == tight) | (leaf[:, :3] == want)).all()
+    else:
+        assert np.array_equal(leaf[:, :3], tight)
+    # the triangle lies inside: every vertex coordinate between the dequantised bounds
+    wc = g.bvh.world_coords
+    v = g.mesh.vertices[g.mesh.triangles[tri]].astype(np.float64)                  # [leaf][3 vertices][xyz]
+    blo = wc.world_origin + (leaf[:, :3] & 0xFFFF).astype(np.float64) * wc.world_scale
+    bhi = wc.world_origin + (leaf[:, :3] >> 16).astype(np.float64) * wc.world_scale
+    slack = 0.02 * wc.world_scale          # (float32 rounding of (v - origin) / scale: a few ulp of the world's extent)
+    assert (v.min(axis=1) >= blo - slack).all() and (v.max(axis=1) <= bhi + slack).all()
 
 
 def test_inner_entries_bound_their_node(built):
