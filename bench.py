@@ -464,16 +464,30 @@ def main():
 
     def timed_leg(prepare, nleg):
         """`nleg` batches through run_step, each between two device synchronisations (the same step definition as the
-        headline); `prepare(i)` returns batch i with its input ready BEFORE the clock starts."""
-        walls = []
+        headline, kernels timed by HIP events on the library's stream); `prepare(i)` returns batch i with its input ready
+        BEFORE the clock starts.  Returns the walls and the summed statistics."""
+        walls, leg_stats = [], {}
         for i in range(nleg):
             b = prepare(i)
             ctx.synchronize()
             t0 = time.perf_counter()
-            run_step(b, False, {})
+            run_step(b, True, leg_stats)
             ctx.synchronize()
             walls.append(time.perf_counter() - t0)
-        return walls
+        return walls, leg_stats
+
+    def leg_roofline(leg, leg_stats, nodes_per_step, tris_per_step, steps_per_photon, nleg):
+        """the ray cast of one leg against the HBM roof: ALGORITHMIC bytes (with the counts given) over the HIP-event
+        time of the leg's ray-cast launches"""
+        ray_s = leg_stats.get('raycast_ms', 0.0) / 1e3
+        if ray_s <= 0:
+            return
+        total = (16.0 * nodes_per_step + 48.0 * tris_per_step + 64 + 8) * steps_per_photon * nphotons * nleg
+        leg['raycast_ms_per_batch'] = 1e3 * ray_s / nleg
+        leg['raycast_avg_launch_ms'] = 1e3 * ray_s / max(1, leg_stats.get('raycast_launches', 0))
+        leg['raycast_algorithmic_GBps'] = total / ray_s / 1e9
+        leg['raycast_frac'] = total / ray_s / 1e9 / HBM_PEAK_GBS
+        leg['physics_ms_per_batch'] = leg_stats.get('physics_ms', 0.0) / nleg
 
     headline_order = rate_stats(step_walls)
     # (the extra legs below run on one GPU only: run_step holds the all-reduce of the per-channel arrays, a collective EVERY
@@ -490,8 +504,9 @@ def main():
     # generation order -- and what the ordering itself costs on the device (it is NOT inside any timed region)
     other_order = sort_cost = None
     if extra_legs:
-        walls = timed_leg(lambda i: leg_batch(i, 30_000, not SORT_DIRECTIONS), nleg)
+        walls, leg_stats = timed_leg(lambda i: leg_batch(i, 30_000, not SORT_DIRECTIONS), nleg)
         other_order = rate_stats(walls)
+        leg_roofline(other_order, leg_stats, nodes_ps, tris_ps, steps_pp, nleg)
         log('%s: %.4g +- %.2g photons/s over %d batches (%.1f +- %.1f ms)' % (
             'photons pre-sorted by direction' if not SORT_DIRECTIONS else 'photons in generation order', other_order['value'], other_order['std'],
             nleg, other_order['ms_per_batch'], other_order['ms_per_batch_std']))
@@ -514,11 +529,21 @@ def main():
     if extra_legs:
         ctx.set_walk('literal')
         try:
-            walls = timed_leg(lambda i: leg_batch(i, 20_000, SORT_DIRECTIONS), nleg)
+            # (the exact walk makes the REFERENCE's tests: its own counts for its algorithmic bytes, from one counting batch)
+            lit_counts = {}
+            ctx.set_counting(True)
+            run_step(leg_batch(0, 19_000, SORT_DIRECTIONS), False, lit_counts)
+            ctx.set_counting(False)
+            walls, leg_stats = timed_leg(lambda i: leg_batch(i, 20_000, SORT_DIRECTIONS), nleg)
         finally:
+            ctx.set_counting(False)
             ctx.set_walk('quad')
         exact_walk = rate_stats(walls)
         exact_walk['kernel'] = 'k_raycast_literal'
+        lit_steps = max(1, lit_counts.get('photon_steps', 0))
+        exact_walk['nodes_per_step'] = lit_counts.get('nodes_visited', 0) / lit_steps
+        exact_walk['triangle_tests_per_step'] = lit_counts.get('triangles_tested', 0) / lit_steps
+        leg_roofline(exact_walk, leg_stats, exact_walk['nodes_per_step'], exact_walk['triangle_tests_per_step'], lit_steps / nphotons, nleg)
         exact_walk['slower_than_default'] = headline_order['value'] / exact_walk['value']
         log('exact (literal reference) walk: %.4g +- %.2g photons/s over %d batches (%.1fx slower than the default walk)' % (
             exact_walk['value'], exact_walk['std'], nleg, exact_walk['slower_than_default']))
