@@ -59,3 +59,29 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', 'tiny', '--gpus', '1', '--steps', '1', '--warmup', '0'],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0 and b'WORLD_SIZE' in p.stderr + p.stdout
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_flow_of_bench_rehearsed_over_gloo():
+    """The whole multi-rank flow of bench.py -- rendezvous, geometry built once by local rank 0 and mapped by the other, the
+    vote on the library communicator, the timed loop between barriers, the max over ranks, one JSON line from rank 0 -- with
+    two ranks sharing this box's one GPU and gloo as the transport (CHROMA_BENCH_BACKEND=gloo: a REHEARSAL, its number means
+    nothing).  Every collective is entered by both ranks or the run hangs into the timeout: this is the test that catches a
+    rank-0-only step drifting into a collective (round 3's first rehearsal did)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CHROMA_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('CHROMA_BENCH_GEOMETRY_CACHE', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--config', 'tiny', '--steps', '2', '--warmup', '1']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, 'exactly one JSON line (rank 0): %r' % lines
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 2 and j['scaling'] == 'weak'
+    assert 'torch.distributed fallback (gloo)' in j['config']['reduction']
+    assert j['config']['exact_walk'] is None and j['cpu_baseline'] is None          # single-GPU legs stay out of multi-rank runs
+    assert j['value'] > 0 and abs(j['value'] * j['ms_per_step'] * 1e-3 / (2 * j['config']['photons_per_gpu_per_step']) - 1.0) < 1e-6
