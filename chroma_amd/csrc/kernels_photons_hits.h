@@ -238,8 +238,12 @@ k_finalize_hits(GeoView g, PhotonView pv, const float4 *final_rec, uint32_t epoc
                 uint32_t *words /* [0] number of hits, [2] OR of the NAN_ABORT bits */)
 {
     __shared__ uint32_t s_wave[256 / WAVE + 1];
+    // (a wave's 64 records are 4 KB in a row: they come in as four coalesced kilobytes and reach their lanes through LDS --
+    //  a lane reading its own record's four float4 touches 64 lines per instruction, as in k_load_working the other way)
+    __shared__ float4 s_stage[256 / WAVE][WAVE * 4];
     const long long base = (long long)blockIdx.x * (COPY_ITEMS * 256);
     const unsigned lane = lane_id(), wave = threadIdx.x / WAVE;
+    float4 *stg = s_stage[wave];
     int ch[COPY_ITEMS];
     uint32_t mine = 0, from_record = 0, aborts = 0;
 #pragma unroll
@@ -247,14 +251,22 @@ k_finalize_hits(GeoView g, PhotonView pv, const float4 *final_rec, uint32_t epoc
         const long long id = base + (long long)k * 256 + threadIdx.x;
         ch[k] = -1;
         uint32_t tb = 0xFFFFFFFFu;
+        if (final_rec) {
+            const long long wave_first = base + (long long)k * 256 + (long long)wave * WAVE;       // (wave-uniform)
+            const long long nrec = min((long long)WAVE, (long long)n - wave_first);                  // records of this wave: <= 0 none
+            const float4 *src = final_rec + 4 * (size_t)max(wave_first, 0ll);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int q = r * WAVE + (int)lane; if (q < 4 * nrec) stg[q] = src[q]; }
+            __builtin_amdgcn_wave_barrier();
+        }
         if (id < (long long)n) {
             uint32_t flags; int lh = -1; float t = 0.f;
             bool have = false;
             float4 f3 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (final_rec) { f3 = final_rec[4 * (size_t)id + 3]; have = __float_as_uint(f3.w) == epoch; }
+            if (final_rec) { f3 = stg[4 * lane + 3]; have = __float_as_uint(f3.w) == epoch; }
             if (have) {
-                const float4 *f = final_rec + 4 * (size_t)id;
-                const float4 f0 = f[0], f1 = f[1], f2 = f[2];
+                const float4 f0 = stg[4 * lane], f1 = stg[4 * lane + 1], f2 = stg[4 * lane + 2];
                 store3(pv.pos, (size_t)id, mk3(f0.x, f0.y, f0.z));
                 store3(pv.dir, (size_t)id, mk3(f1.x, f1.y, f1.z));
                 store3(pv.pol, (size_t)id, mk3(f2.x, f2.y, f2.z));
