@@ -143,6 +143,8 @@ struct chroma_ctx {
     uint64_t pool_hits = 0, pool_misses = 0;
     // ---- host -> device uploads: a second stream and a ring of pinned staging buffers (chroma_upload) ----
     hipStream_t copy_stream = nullptr;
+    hipStream_t aux_stream = nullptr;          // k_finalize_hits beside the tail kernel (launch_tail)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::mutex stage_mu;
     static constexpr int STAGE_N = 3;
     static constexpr size_t STAGE_BYTES = 64u << 20;
@@ -494,8 +496,11 @@ static int launch_split_step(chroma_ctx *ctx, const CallOpts &co, chroma_geometr
 // *done when the geometry has a wide tree the kernel can walk; otherwise leaves *done false.
 static int launch_tail(chroma_ctx *ctx, const CallOpts &co, chroma_geometry *geom, PhotonView pv, long long n_upper, const uint32_t *in_q,
                        uint32_t *out_q, const float4 *work_in, chroma_rng rng, int nsteps, int use_weights, int scatter_first,
-                       hipEvent_t *ev, bool *done, uint32_t first_n = 0)
+                       hipEvent_t *ev, bool *done, uint32_t first_n = 0, const HitsOut *beside = nullptr, uint64_t nphotons = 0)
 {
+    // (`beside`: a call that ends in k_finalize_hits -- that pass runs on the context's auxiliary stream WHILE the tail kernel
+    //  finishes the last photons, which are stamped first so that it leaves them to the tail kernel; the two meet again
+    //  before the call reads its result words)
     *done = false;
     if (!geom->view.wnodes || geom->wide_stack_need > COOP_STACK + COOP_SPILL || geom->stack_need > STACK_LDS + STACK_SCRATCH)
         return CHROMA_OK;
@@ -508,14 +513,31 @@ static int launch_tail(chroma_ctx *ctx, const CallOpts &co, chroma_geometry *geo
     StepState *st = ctx->d_step;
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, ctx->stream, in_q, out_q, st,
                        use_weights ? 0xFFFFFFFFu : (uint32_t)(PROP_BLOCK * 16 * 8), first_n);
+    HitsOut ho; memset(&ho, 0, sizeof ho);
+    uint32_t *words = nullptr;
+    if (beside) {
+        ho = *beside;
+        words = ctx->d_words;
+        const uint32_t tail_mark = ctx->final_epoch | 0x80000000u;
+        HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 12, ctx->stream));
+        if (ctx->final_use)
+            hipLaunchKernelGGL(k_mark_tail, dim3(32), dim3(256), 0, ctx->stream, in_q, ctx->final_use, tail_mark);
+        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+        const unsigned blocks = (unsigned)((nphotons + COPY_ITEMS * 256 - 1) / (COPY_ITEMS * 256));
+        hipLaunchKernelGGL(k_finalize_hits, dim3(blocks), dim3(256), 0, ctx->aux_stream, geom->view, pv, (const float4 *)ctx->final_use, ctx->final_epoch,
+                           nphotons, ho, ctx->d_words, tail_mark);
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+    }
     if (ev) { HIP_TRY(hipEventRecord(ev[0], ctx->stream)); HIP_TRY(hipEventRecord(ev[1], ctx->stream)); }
     if (co.counting)
         hipLaunchKernelGGL((k_tail_coop<true>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in,
-                           rng.seed, rng.photon_id_base, nsteps, use_weights, scatter_first, ctx->coop_spill, ctx->d_counters);
+                           rng.seed, rng.photon_id_base, nsteps, use_weights, scatter_first, ctx->coop_spill, ctx->d_counters, ho, words);
     else
         hipLaunchKernelGGL((k_tail_coop<false>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in,
-                           rng.seed, rng.photon_id_base, nsteps, use_weights, scatter_first, ctx->coop_spill, ctx->d_counters);
+                           rng.seed, rng.photon_id_base, nsteps, use_weights, scatter_first, ctx->coop_spill, ctx->d_counters, ho, words);
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+    if (beside) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     HIP_TRY(hipGetLastError());
     *done = true;
     return CHROMA_OK;
@@ -737,6 +759,9 @@ int chroma_init(int device, chroma_ctx **out)
     ctx->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -805,6 +830,9 @@ int chroma_shutdown(chroma_ctx *ctx)
     for (int i = 0; i < chroma_ctx::STAGE_N; i++) { if (ctx->stage[i]) hipHostFree(ctx->stage[i]); if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]); }
     for (int i = 0; i < chroma_ctx::STAGE_N; i++) { if (ctx->stage_down[i]) hipHostFree(ctx->stage_down[i]); if (ctx->stage_down_ev[i]) hipEventDestroy(ctx->stage_down_ev[i]); }
     hipStreamDestroy(ctx->copy_stream);
+    if (ctx->aux_stream) { hipStreamSynchronize(ctx->aux_stream); hipStreamDestroy(ctx->aux_stream); }
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->queue_a) hipFree(ctx->queue_a);
     if (ctx->queue_b) hipFree(ctx->queue_b);
     if (ctx->wide_spill) hipFree(ctx->wide_spill);
@@ -1743,13 +1771,23 @@ static int propagate_impl(chroma_ctx *ctx, chroma_geometry *geom, const chroma_p
     if (use_records) {
         rc = ensure_final_records(ctx, nphotons); if (rc) return rc;
         ctx->final_epoch++;
-        if (ctx->final_epoch == 0u) {            // (wrapped: no stale record may look current)
+        if (ctx->final_epoch == 0u || ctx->final_epoch >= 0x7FFFFFFFu) {            // (wrapped -- the top bit marks the tail kernel's photons --: no stale record may look current)
             HIP_TRY(hipMemsetAsync(ctx->final_rec, 0, ctx->final_capacity * 4 * sizeof(float4), ctx->stream));
             ctx->final_epoch = 1u;
         }
         ctx->final_use = ctx->final_rec;
     }
     struct FinalGuard { chroma_ctx *c; ~FinalGuard() { c->final_use = nullptr; } } final_guard{ctx};
+    // where the call's last pass (k_finalize_hits) puts the hits, if it runs at all
+    const bool finalize = use_records || hr != nullptr;
+    bool finalized = false;              // it has been launched already, beside the tail kernel (launch_tail)
+    HitsOut ho; memset(&ho, 0, sizeof ho);
+    if (hr) {
+        ho.want = 1;
+        ho.detection_state = hr->detection_state;
+        if (hr->dst) { ho.dst = to_view(hr->dst); ho.channels = hr->d_channels; ho.capacity = hr->capacity; }
+        ho.hit_count = hr->d_hit_count; ho.earliest = hr->d_hit_count ? hr->d_earliest_time_bits : nullptr;
+    }
 
     double kernel_ms = 0.0, raycast_ms = 0.0, physics_ms = 0.0, packet_ms = 0.0;
     uint64_t launches = 0, raycast_launches = 0, physics_launches = 0, packet_launches = 0;
@@ -1806,9 +1844,10 @@ static int propagate_impl(chroma_ctx *ctx, chroma_geometry *geom, const chroma_p
                 bool launched = false;
                 rc = launch_tail(ctx, co, geom, pv, n_upper, in_q, out_q, work_in, rng, max_steps - step, use_weights,
                                  step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 6 * step : nullptr, &launched,
-                                 step == 0 ? (uint32_t)nphotons : 0u);
+                                 step == 0 ? (uint32_t)nphotons : 0u, finalize ? &ho : nullptr, (uint64_t)nphotons);
                 if (rc) return rc;
                 if (launched) {
+                    finalized = finalize;
                     if (time_kernels) { tail_step = step; steps_timed = step + 1; }
                     step = max_steps;
                     tail_done = true;            // (it wrote every photon it held back to the caller's arrays)
@@ -1894,20 +1933,16 @@ static int propagate_impl(chroma_ctx *ctx, chroma_geometry *geom, const chroma_p
         }
     }
     uint32_t word = 0;
-    if (use_records || hr) {
-        // one pass: records -> the caller's arrays, abort word, hit count + compaction + per-channel arrays (k_finalize_hits)
-        HitsOut ho; memset(&ho, 0, sizeof ho);
-        if (hr) {
-            ho.want = 1;
-            ho.detection_state = hr->detection_state;
-            if (hr->dst) { ho.dst = to_view(hr->dst); ho.channels = hr->d_channels; ho.capacity = hr->capacity; }
-            ho.hit_count = hr->d_hit_count; ho.earliest = hr->d_hit_count ? hr->d_earliest_time_bits : nullptr;
+    if (finalize) {
+        // one pass: records -> the caller's arrays, abort word, hit count + compaction + per-channel arrays (k_finalize_hits);
+        // a call that ended in the tail kernel has run it beside that kernel already (launch_tail)
+        if (!finalized) {
+            HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 12, ctx->stream));
+            const unsigned blocks = (unsigned)((nphotons + COPY_ITEMS * 256 - 1) / (COPY_ITEMS * 256));
+            hipLaunchKernelGGL(k_finalize_hits, dim3(blocks), dim3(256), 0, ctx->stream, geom->view, pv, (const float4 *)ctx->final_use, ctx->final_epoch,
+                               (uint64_t)nphotons, ho, ctx->d_words, 0u);
+            HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipMemsetAsync(ctx->d_words, 0, 12, ctx->stream));
-        const unsigned blocks = (unsigned)((nphotons + COPY_ITEMS * 256 - 1) / (COPY_ITEMS * 256));
-        hipLaunchKernelGGL(k_finalize_hits, dim3(blocks), dim3(256), 0, ctx->stream, geom->view, pv, (const float4 *)ctx->final_use, ctx->final_epoch,
-                           (uint64_t)nphotons, ho, ctx->d_words);
-        HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ctx->h_words, ctx->d_words, 12, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         word = ctx->h_words[2];

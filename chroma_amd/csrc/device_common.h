@@ -96,6 +96,23 @@ struct DeviceCounters {   // accumulated with one atomic per wave
     unsigned long long packet_rays, packet_nodes, packet_tris;      // k_raycast_packet's share of the two counts above (counting builds)
 };
 
+// ---- hits ---------------------------------------------------------------------------------------------------------
+// the channel a photon was detected on, or -1 (propagate.cu:157-171: the flag, a last hit triangle, a solid with a channel)
+__device__ inline int hit_channel(const GeoView &g, uint32_t history, int triangle_id, uint32_t detection_state)
+{
+    if (!(history & detection_state)) return -1;
+    if (triangle_id <= -1) return -1;
+    uint32_t solid_id = g.solid_id_map[triangle_id];
+    return g.solid_id_to_channel_index[solid_id];
+}
+
+// where the hits of a chroma_propagate_hits call go (k_finalize_hits, and k_tail_coop for the photons it finishes)
+struct HitsOut {
+    PhotonView dst; int32_t *channels; uint32_t capacity;
+    uint32_t *hit_count, *earliest;
+    uint32_t detection_state; int want;
+};
+
 // ---- wave-level helpers --------------------------------------------------------------------
 __device__ inline unsigned lane_id() { return __lane_id(); }
 

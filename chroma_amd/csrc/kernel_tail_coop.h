@@ -130,8 +130,10 @@ template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) void
 k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const float4 *work_in,
             uint64_t seed, uint64_t id_base, int max_steps, int use_weights, int scatter_first, uint2 *spill_base,
-            DeviceCounters *counters)
+            DeviceCounters *counters, HitsOut h, uint32_t *words)
 {
+    // (`words` != NULL: a chroma_propagate_hits call whose k_finalize_hits runs BESIDE this kernel on another stream and leaves
+    //  this kernel's photons alone (k_mark_tail): their abort bits and hits are reported from here)
     __shared__ uint32_t s_coop[8 * COOP_STRIDE];
     __shared__ uint32_t s_walk[TRAV_LDS_WORDS(STACK_LDS, PROP_BLOCK)];
     const int nthreads = (int)st->n, renorm = (int)st->renorm;
@@ -227,6 +229,29 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const float4 *work_in
         pv.flags[photon_id] = p.history;
         pv.last_hit_triangles[photon_id] = p.last_hit_triangle;
         pv.weights[photon_id] = p.weight;
+        if (words) {
+            if (p.history & CHROMA_NAN_ABORT) atomicOr(words + 2, CHROMA_NAN_ABORT);
+            const int ch = h.want ? hit_channel(g, p.history, p.last_hit_triangle, h.detection_state) : -1;
+            if (ch >= 0) {
+                const uint32_t off = atomicAdd(words, 1u);
+                if (h.channels && off < h.capacity) {
+                    store3(h.dst.pos, off, p.position);
+                    store3(h.dst.dir, off, p.direction);
+                    store3(h.dst.pol, off, p.polarization);
+                    h.dst.wavelengths[off] = p.wavelength;
+                    h.dst.t[off] = p.time;
+                    h.dst.flags[off] = p.history;
+                    h.dst.last_hit_triangles[off] = p.last_hit_triangle;
+                    h.dst.weights[off] = p.weight;
+                    h.dst.evidx[off] = pv.evidx[photon_id];
+                    h.channels[off] = ch;
+                }
+                if (h.hit_count) {
+                    atomicAdd(&h.hit_count[ch], 1u);
+                    if (h.earliest) atomicMin(&h.earliest[ch], __float_as_uint(p.time));
+                }
+            }
+        }
     }
 
     if (COUNT) {
@@ -239,4 +264,13 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const float4 *work_in
             if (sx) atomicAdd(&counters->stack_spills, sx);
         }
     }
+}
+
+// the photons the tail kernel is about to finish: their final-record slots are stamped, so that the k_finalize_hits that runs
+// beside the tail kernel leaves them alone (slot 0 of the queue = tail index, as everywhere)
+__global__ void k_mark_tail(const uint32_t *queue, float4 *final_rec, uint32_t tail_mark)
+{
+    const uint32_t n = queue[0] - 1u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        final_rec[4 * (size_t)queue[1 + i] + 3] = make_float4(0.f, 0.f, 0.f, __uint_as_float(tail_mark));
 }

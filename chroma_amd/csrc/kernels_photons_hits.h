@@ -122,13 +122,6 @@ __global__ void k_copy_photon_queue(PhotonView src, PhotonView dst, int first_ph
     copy_photon(src, queue[offset], dst, offset);
 }
 
-__device__ inline int hit_channel(const GeoView &g, uint32_t history, int triangle_id, uint32_t detection_state)
-{
-    if (!(history & detection_state)) return -1;
-    if (triangle_id <= -1) return -1;
-    uint32_t solid_id = g.solid_id_map[triangle_id];
-    return g.solid_id_to_channel_index[solid_id];
-}
 
 // count_photon_hits (propagate.cu:147-174): grid-stride, one atomic per block
 __global__ __launch_bounds__(256) void
@@ -228,14 +221,9 @@ __global__ void k_channel_hits(GeoView g, const uint32_t *flags, const int32_t *
 // from the arrays.  Detected photons that belong to a channel are counted, compacted into `dst` with their
 // channel (one atomic per block of COPY_ITEMS * 256 photons, as k_copy_hits: the order of the blocks is the order of their atomics), and bump the per-channel count / earliest-time arrays.
 // final_rec == NULL: everything comes from the arrays (the fused form of k_count_hits + k_copy_hits + k_channel_hits).
-struct HitsOut {
-    PhotonView dst; int32_t *channels; uint32_t capacity;
-    uint32_t *hit_count, *earliest;
-    uint32_t detection_state; int want;
-};
 __global__ __launch_bounds__(256) void
 k_finalize_hits(GeoView g, PhotonView pv, const float4 *final_rec, uint32_t epoch, uint64_t n, HitsOut h,
-                uint32_t *words /* [0] number of hits, [2] OR of the NAN_ABORT bits */)
+                uint32_t *words /* [0] number of hits, [2] OR of the NAN_ABORT bits */, uint32_t tail_mark)
 {
     __shared__ uint32_t s_wave[256 / WAVE + 1];
     // (a wave's 64 records are 4 KB in a row: they come in as four coalesced kilobytes and reach their lanes through LDS --
@@ -265,6 +253,11 @@ k_finalize_hits(GeoView g, PhotonView pv, const float4 *final_rec, uint32_t epoc
             bool have = false;
             float4 f3 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (final_rec) { f3 = stg[4 * lane + 3]; have = __float_as_uint(f3.w) == epoch; }
+            // (a photon the tail kernel holds -- it may be finishing it right now, on the other stream -- is the tail kernel's
+            //  to store, to count and to report: k_mark_tail stamped its record before this kernel started)
+            if (final_rec && tail_mark != 0u && __float_as_uint(f3.w) == tail_mark) {
+                flags = 0u;
+            } else
             if (have) {
                 const float4 f0 = stg[4 * lane], f1 = stg[4 * lane + 1], f2 = stg[4 * lane + 2];
                 store3(pv.pos, (size_t)id, mk3(f0.x, f0.y, f0.z));
