@@ -17,6 +17,4 @@ int chroma_internal_dtoh(chroma_ctx *ctx, void *h_dst, const void *d_src, size_t
 int chroma_internal_htod(chroma_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes);
 // (bvh_device.hip) d_order[n] = the photons 0..n-1 ordered by a 16-bit cell of their direction; queued on the context's stream
 int chroma_internal_direction_order(chroma_ctx *ctx, const float *d_dir, uint32_t n, uint32_t *d_order);
-// (bvh_device.hip) exclusive prefix sums of n words, queued on the context's stream
-int chroma_internal_exclusive_scan(chroma_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t n);
 }

@@ -103,72 +103,6 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
     }
 }
 
-// ---- the working set taken up BY DIRECTION CELL ------------------------------------------------------------------------
-// How long the first launches of a call take depends on whether neighbouring queue slots hold neighbouring rays (29 ms against
-// 37 ms for the first ray cast of a 1e8-photon bomb at C3, 19 against 24 ms for k_physics).  A caller's photons come in no
-// particular order, and sorting them costs more than it wins as long as the sort moves the ten arrays (round 3: +36 ms).  Here
-// nothing is sorted and nothing is gathered: the arrays are still READ in their own order, coalesced, and every photon's two
-// 64-byte records are WRITTEN to a slot inside the range of its direction cell -- a counting sort by a 12-bit cell with the
-// digit counted per block (LDS histogram), one exclusive scan over (cell, block), and the rank inside a (cell, block) pair
-// from an LDS counter: no global atomics, one more pass over the directions.  Which photon sits in which slot changes
-// NOTHING in the results (streams are keyed by photon id, a photon ends up in the caller's arrays at its id).
-#ifndef BUCKET_CELLS
-#define BUCKET_CELLS 4096         // 64 x 64 cells of an octahedral map of the sphere, Morton-interleaved: 3 degrees across
-#endif
-#define BUCKET_BLOCK 512
-__device__ inline uint32_t direction_cell(float x, float y, float z)
-{
-    const float s = fabsf(x) + fabsf(y) + fabsf(z);
-    float u = s > 0.0f ? x / s : 0.0f, v = s > 0.0f ? y / s : 0.0f;
-    if (z < 0.0f) { const float uu = (1.0f - fabsf(v)) * (u < 0.0f ? -1.0f : 1.0f), vv = (1.0f - fabsf(u)) * (v < 0.0f ? -1.0f : 1.0f); u = uu; v = vv; }
-    const uint32_t iu = (uint32_t)fminf(63.0f, fmaxf(0.0f, (u * 0.5f + 0.5f) * 64.0f)), iv = (uint32_t)fminf(63.0f, fmaxf(0.0f, (v * 0.5f + 0.5f) * 64.0f));
-    uint32_t m = 0;
-#pragma unroll
-    for (int b = 0; b < 6; b++) m |= ((iu & (1u << b)) << b) | ((iv & (1u << b)) << (b + 1));
-    return m;        // (a NaN direction lands in some cell: any cell is fine)
-}
-// hist[cell * gridDim.x + block] = live photons of the block's tile [block * tile, (block + 1) * tile) in that cell
-__global__ __launch_bounds__(BUCKET_BLOCK) void
-k_bucket_count(PhotonView pv, uint64_t n, uint32_t tile, uint32_t *hist)
-{
-    __shared__ uint32_t s_cnt[BUCKET_CELLS];
-    for (uint32_t c = threadIdx.x; c < BUCKET_CELLS; c += BUCKET_BLOCK) s_cnt[c] = 0u;
-    __syncthreads();
-    const uint64_t lo = (uint64_t)blockIdx.x * tile, hi = min(n, lo + tile);
-    for (uint64_t j = lo + threadIdx.x; j < hi; j += BUCKET_BLOCK) {
-        if (pv.flags[j] & CHROMA_TERMINAL_MASK) continue;
-        atomicAdd(&s_cnt[direction_cell(pv.dir[3 * j], pv.dir[3 * j + 1], pv.dir[3 * j + 2])], 1u);
-    }
-    __syncthreads();
-    for (uint32_t c = threadIdx.x; c < BUCKET_CELLS; c += BUCKET_BLOCK) hist[(size_t)c * gridDim.x + blockIdx.x] = s_cnt[c];
-}
-// offsets = exclusive scan of hist over (cell, block) with the total behind the last entry
-__global__ __launch_bounds__(BUCKET_BLOCK) void
-k_load_working_bucketed(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t n, uint32_t tile, const uint32_t *offsets, float4 *rays)
-{
-    __shared__ uint32_t s_at[BUCKET_CELLS];
-    for (uint32_t c = threadIdx.x; c < BUCKET_CELLS; c += BUCKET_BLOCK) s_at[c] = offsets[(size_t)c * gridDim.x + blockIdx.x];
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) queue[0] = offsets[(size_t)BUCKET_CELLS * gridDim.x] + 1u;      // slot 0 = tail
-    const uint64_t lo = (uint64_t)blockIdx.x * tile, hi = min(n, lo + tile);
-    for (uint64_t j = lo + threadIdx.x; j < hi; j += BUCKET_BLOCK) {
-        const uint32_t flags = pv.flags[j];
-        if (flags & CHROMA_TERMINAL_MASK) continue;                  // already terminal: left out, untouched (propagate.cu:258)
-        const uint32_t photon_id = (uint32_t)j;
-        const v3 pos = load3(pv.pos, j), dir = load3(pv.dir, j), pol = load3(pv.pol, j);
-        const uint32_t slot = atomicAdd(&s_at[direction_cell(dir.x, dir.y, dir.z)], 1u);
-        int lh = pv.last_hit_triangles[j];
-        lh = (lh >= 0 && (uint32_t)lh < g.ntriangles) ? (int)g.tri_to_dev[lh] : -1;
-        queue[1 + (size_t)slot] = photon_id;
-        float4 *w = work + 4 * (size_t)slot;
-        w[0] = make_float4(pos.x, pos.y, pos.z, pv.wavelengths[j]);
-        w[1] = make_float4(dir.x, dir.y, dir.z, pv.t[j]);
-        w[2] = make_float4(pol.x, pol.y, pol.z, pv.weights[j]);
-        w[3] = make_float4(__uint_as_float(flags), __uint_as_float(pv.rng_counters[j]), __int_as_float(lh), __uint_as_float(photon_id));
-        if (rays) make_ray_record(g, rays + 4 * (size_t)slot, pos, dir, 1, lh);
-    }
-}
-
 // the photons still alive when the call ends go back to the caller's arrays
 __global__ void k_store_working(GeoView g, PhotonView pv, const uint32_t *queue, const float4 *work)
 {

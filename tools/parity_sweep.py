@@ -1,5 +1,6 @@
 """Large-sample parity sweep on the GPU box: engine vs oracle, bit for bit, on random bombs and on rays
-aimed at mesh vertices/edges from several origins.  usage: parity_sweep.py [tiny|lite|detector|c3|c5] [photons per batch] [batches]"""
+aimed at mesh vertices/edges from several origins.  usage: parity_sweep.py [tiny|lite|detector|c3|c5] [photons per batch] [batches] [exact]
+(`exact`: through the exact walk, GPUPhotons.propagate(exact=True) -- then the aimed rays must not differ either)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +14,7 @@ from chroma_amd.gpu.geometry import pack_geometry
 config = sys.argv[1] if len(sys.argv) > 1 else 'tiny'
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 5_000_000
 batches = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+exact = len(sys.argv) > 4 and sys.argv[4] == 'exact'
 geo = create_geometry_from_obj({'tiny': demo.tiny, 'lite': demo.detector_lite, 'detector': demo.detector, 'c3': demo.detector29k,
                                 'c5': demo.scintillator_stress}[config]())
 pk = pack_geometry(geo)
@@ -25,7 +27,7 @@ FIELDS = ('flags', 'last_hit_triangles', 'pos', 'dir', 'pol', 't', 'wavelengths'
 def compare(ph, seed, what):
     rs = gpu.get_rng_states(64, seed=seed)
     gp = gpu.GPUPhotons(ph)
-    t0 = time.time(); gp.propagate(gg, rs, max_steps=100); got = gp.get(); t1 = time.time()
+    t0 = time.time(); gp.propagate(gg, rs, max_steps=100, exact=exact); got = gp.get(); t1 = time.time()
     want, _, _ = oracle.propagate(pk, ph, seed=seed, max_steps=100, nthreads=min(64, len(os.sched_getaffinity(0))))
     t2 = time.time()
     bad = np.zeros(len(ph), dtype=bool)
@@ -55,4 +57,4 @@ for origin in ([0, 0, 0], [300.0, -200.0, 150.0], [0.0, 0.0, 1200.0]):
     pol = np.cross(d, np.roll(d, 1, axis=1) + 1e-3); pol /= np.linalg.norm(pol, axis=1)[:, None]
     ph = Photons(np.tile(np.asarray(origin, dtype=float), (len(d), 1)), d, pol, np.full(len(d), wl0))
     total += compare(ph, 77, 'aimed from %s' % (origin,))
-print('TOTAL differing photons:', total)
+print('TOTAL differing photons (%s walk):' % ('exact' if exact else 'default'), total)

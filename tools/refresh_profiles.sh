@@ -2,7 +2,8 @@
 # One GPU-box pass that refreshes the judged artefacts: GPU tests, the bench lines of every config, the
 # rocprofv3 kernel summary of the default bench command and its HBM-traffic counters (FETCH_SIZE / WRITE_SIZE in
 # separate --pmc passes, no trace flags beside them).  usage: tools/refresh_profiles.sh OUTDIR
-# (a gpurun call is limited to 20 minutes: PART=1 runs the tests and the bench lines, PART=2 the profiles; default both)
+# (a gpurun call is limited to 20 minutes: PART=1 runs the tests and the bench lines, PART=2 the profiles of the default walk,
+#  PART=3 the exact walk's profiles and the measured variants of the contract; default 1 and 2)
 set -u
 out=$1
 part=${PART:-12}
@@ -16,7 +17,7 @@ for cfg in tiny lite c5 detector; do
   python bench.py --config $cfg > $out/bench_$cfg.json 2> $out/bench_$cfg.log || exit 1
 done
 fi
-if [[ $part != *2* ]]; then rm -rf /dev/shm/chroma_geo_cache; cat $out/bench_*.json; exit 0; fi
+if [[ $part == *2* ]]; then
 export CHROMA_BENCH_NO_EXACT=1      # (the profiles are of the default walk: no extra batch through the literal one)
 # (the profiles are of the propagate path: the geometry comes from the cache -- filled here if PART=2 runs on a box of its own --
 #  so that the builders' kernels, run once per geometry, do not head the per-kernel list)
@@ -47,3 +48,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_geo -- pyth
 rm -rf $out/rocprof_geo
 rm -rf /dev/shm/chroma_geo_cache
 cat $out/bench_*.json
+fi
+if [[ $part == *3* ]]; then
+# the exact walk (CHROMA_WALK=literal): bench line, rocprofv3 summary, SQ + traffic counters; the variants of SURVEY 8(d)
+tools/prof_literal.sh $out/literal
+mv $out/literal/bench_literal.json $out/bench_c3_literal.json; mv $out/literal/bench_literal.log $out/bench_c3_literal.log
+mv $out/literal/rocprof_literal_summary.txt $out/rocprof_c3_literal_summary.txt; mv $out/literal/pmc/summary.txt $out/pmc_literal_sq_traffic.txt
+rm -rf $out/literal
+tools/bench_variants.sh $out/variants
+fi
