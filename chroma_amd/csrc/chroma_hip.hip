@@ -307,7 +307,7 @@ static bool step_uses_quad_walk(const CallOpts &co, const chroma_geometry *geom)
 // (a short list: a small grid), 2 every slot with the ray cast's results taken as they are (the exact walk).
 static void launch_physics(chroma_ctx *ctx, const CallOpts &co, chroma_geometry *geom, const PhotonView &pv, long long n_upper,
                            const float4 *work_in, uint32_t *out_q, float4 *work_out, chroma_rng rng, int use_weights, int scatter_first,
-                           int fixup, float4 *rays_next)
+                           int fixup, float4 *rays_next, int literal_rays = 0)
 {
     StepState *st = ctx->d_step;
     const bool plain = geom->view.plain_optics != 0;      // (no re-emitting component, default surface model only)
@@ -333,11 +333,11 @@ static void launch_physics(chroma_ctx *ctx, const CallOpts &co, chroma_geometry 
     if (plain)
         hipLaunchKernelGGL((k_physics<false>), dim3(blocks), dim3(PHYS_BLOCK_OF(false)), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                            ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                           ctx->retry_list, fixup, pc, rays_next, ctx->final_use, ctx->final_epoch);
+                           ctx->retry_list, fixup, pc, rays_next, ctx->final_use, ctx->final_epoch, literal_rays);
     else
         hipLaunchKernelGGL((k_physics<true>), dim3(blocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, out_q, work_out,
                            ctx->hit_triangle, ctx->hit_distance, rng.seed, rng.photon_id_base, use_weights, scatter_first,
-                           ctx->retry_list, fixup, pc, rays_next, ctx->final_use, ctx->final_epoch);
+                           ctx->retry_list, fixup, pc, rays_next, ctx->final_use, ctx->final_epoch, literal_rays);
 }
 
 // `rays_ready`: the records of this step are in ctx->rays already (written by k_load_working or by the k_physics of
@@ -367,9 +367,14 @@ static int launch_split_step(chroma_ctx *ctx, const CallOpts &co, chroma_geometr
             HIP_TRY(hipSetDevice(ctx->device));
             HIP_TRY(ctx_malloc(ctx, (void **)&ctx->coop_spill, spill_entries(ctx) * sizeof(uint2)));
         }
-        unsigned sblocks = (unsigned)std::min<long long>((n_upper + 255) / 256, (long long)ctx->physics_blocks * 4);
-        hipLaunchKernelGGL(k_ray_setup, dim3(sblocks), dim3(256), 0, ctx->stream, geom->view, work_in, st, ctx->rays,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, &st->retry, lane_walk ? 0 : 1);
+        // (the exact walk chains its ray records from kernel to kernel like the default walk: k_load_working writes the first
+        //  step's, k_physics the next step's while the photon is in its registers; LITERAL_LANE keeps the k_ray_setup pass)
+        const bool chained_lit = !lane_walk && rays_ready;
+        if (!chained_lit) {
+            unsigned sblocks = (unsigned)std::min<long long>((n_upper + 255) / 256, (long long)ctx->physics_blocks * 4);
+            hipLaunchKernelGGL(k_ray_setup, dim3(sblocks), dim3(256), 0, ctx->stream, geom->view, work_in, st, ctx->rays,
+                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, &st->retry, lane_walk ? 0 : 1);
+        }
         if (ev) { HIP_TRY(hipEventRecord(ev[3], ctx->stream)); HIP_TRY(hipEventRecord(ev[5], ctx->stream)); }
         if (lane_walk) {
             const unsigned lblocks = (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK, (long long)ctx->persistent_waves);
@@ -384,20 +389,21 @@ static int launch_split_step(chroma_ctx *ctx, const CallOpts &co, chroma_geometr
             const unsigned rblocks = (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK, 8 * 256);
             if (co.counting) {
                 hipLaunchKernelGGL((k_raycast_literal<true>), dim3(lwaves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
-                                   ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk);
+                                   ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, chained_lit ? 1 : 0, ctx->retry_list);
                 hipLaunchKernelGGL((k_raycast_retry<true>), dim3(rblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
                                    ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
             } else {
                 hipLaunchKernelGGL((k_raycast_literal<false>), dim3(lwaves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
-                                   ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk);
+                                   ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, chained_lit ? 1 : 0, ctx->retry_list);
                 hipLaunchKernelGGL((k_raycast_retry<false>), dim3(rblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
                                    ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
             }
         }
         if (ev) HIP_TRY(hipEventRecord(ev[1], ctx->stream));
-        launch_physics(ctx, co, geom, pv, n_upper, work_in, out_q, work_out, rng, use_weights, scatter_first, 2, nullptr);
+        launch_physics(ctx, co, geom, pv, n_upper, work_in, out_q, work_out, rng, use_weights, scatter_first, 2, lane_walk ? nullptr : ctx->rays_b, 1);
         if (ev) { HIP_TRY(hipEventRecord(ev[4], ctx->stream)); HIP_TRY(hipEventRecord(ev[2], ctx->stream)); }
         HIP_TRY(hipGetLastError());
+        if (!lane_walk) std::swap(ctx->rays, ctx->rays_b);       // (what k_physics wrote is the next step's input)
         return CHROMA_OK;
     }
     const bool pair = co.walk == CHROMA_WALK_PAIR && have_wide && geom->wide_stack_need <= PAIR_STACK + COOP_SPILL;
@@ -1803,6 +1809,8 @@ static int propagate_impl(chroma_ctx *ctx, chroma_geometry *geom, const chroma_p
     // count only now and then, to stop early, to shrink the grids and to hand the last photons to the
     // fused tail kernel.  The live photons travel in the dense working set (k_load_working).
     const bool device_steps = co.split_tail != 0;
+    // the walks whose steps chain their ray records from kernel to kernel (k_load_working -> ray cast -> k_physics -> ...)
+    const bool chains_rays = step_uses_quad_walk(co, geom) || co.walk == CHROMA_WALK_LITERAL;
     if (device_steps) {
         HIP_TRY(hipMemsetAsync(ctx->d_step, 0, sizeof(StepState), ctx->stream));
         hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, ctx->stream, in_q, 1u);
@@ -1820,8 +1828,8 @@ static int propagate_impl(chroma_ctx *ctx, chroma_geometry *geom, const chroma_p
             if (step_uses_quad_walk(co, geom)) { rc = propagate_order(ctx, co, pv, nphotons, ncopies, &d_order); if (rc) return rc; }
             hipLaunchKernelGGL(k_load_working, dim3(blocks), dim3(PHYS_BLOCK), 0, ctx->stream, geom->view, pv, in_q, work_in,
                                (uint64_t)nphotons, ncopies, (uint32_t)(nphotons / ncopies),
-                               step_uses_quad_walk(co, geom) ? ctx->rays : nullptr, (probe && co.packet == 2) ? ctx->d_words + 5 : nullptr,
-                               (const uint32_t *)d_order);
+                               chains_rays ? ctx->rays : nullptr, (probe && co.packet == 2) ? ctx->d_words + 5 : nullptr,
+                               (const uint32_t *)d_order, co.walk == CHROMA_WALK_LITERAL ? 1 : 0);
             if (d_order) { chroma_free(ctx, d_order); reordered = nphotons; }      // (parked until the stream has passed this point)
 #if CHROMA_EXPERIMENTAL
             if (probe)
@@ -1856,7 +1864,7 @@ static int propagate_impl(chroma_ctx *ctx, chroma_geometry *geom, const chroma_p
             }
             rc = launch_split_step(ctx, co, geom, pv, n_upper, in_q, out_q, work_in, work_out, rng, use_weights,
                                    step == 0 ? scatter_first : 0, time_kernels ? ctx->step_events.data() + 6 * step : nullptr,
-                                   step == 0 ? (uint32_t)nphotons : 0u, step_uses_quad_walk(co, geom), step == 0 && packet_offered);
+                                   step == 0 ? (uint32_t)nphotons : 0u, chains_rays, step == 0 && packet_offered);
             if (rc) return rc;
             if (time_kernels) steps_timed = step + 1;
             step++;

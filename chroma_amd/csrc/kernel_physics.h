@@ -25,8 +25,9 @@ __global__ __launch_bounds__(PHYS_BLOCK_OF(FULL)) __attribute__((amdgpu_waves_pe
 k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32_t *output_queue, float4 *work_out,
           const int32_t *hit_triangle, const float *hit_distance, uint64_t seed, uint64_t id_base,
           int use_weights, int scatter_first, uint32_t *retry_list, int fixup, DeviceCounters *counters, float4 *rays_next,
-          float4 *final_rec = nullptr, uint32_t epoch = 0u)
+          float4 *final_rec = nullptr, uint32_t epoch = 0u, int literal_rays = 0)
 {
+    // (`literal_rays`: the survivors' next ray records carry 1/d and -o/d, what k_raycast_literal reads: the exact walk)
     // Two passes per step.  Main pass (fixup = 0): every slot of the working set; a slot the ray cast
     // handed to the strict walk (HIT_RETRY) is left alone, and so is a hit that is not REGULAR
     // (record_hit_is_regular, propagate_device.h): its slot joins retry_list.  Fix-up pass (fixup = 1),
@@ -179,7 +180,7 @@ k_physics(GeoView g, PhotonView pv, StepState *st, const float4 *work_in, uint32
         w[3] = make_float4(__uint_as_float(p.history), __uint_as_float(counter), __int_as_float(last_hit_record), __uint_as_float(photon_id));
         // the survivor's ray for the next step (see k_ray_setup): the next launch re-normalises unless the reference's
         // last launch has begun -- which k_step_begin of THIS step has already decided
-        if (rays_next) make_ray_record(g, rays_next + 4 * (size_t)(at - 1u), p.position, p.direction, renorm_next, last_hit_record);
+        if (rays_next) make_ray_record(g, rays_next + 4 * (size_t)(at - 1u), p.position, p.direction, renorm_next, last_hit_record, literal_rays != 0);
     }
     __syncthreads();        // s_counts is reused by the next round
     }

@@ -81,8 +81,10 @@ __device__ inline float box_tmin_exact(uint4 nd, float ws, float wox, float woy,
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(LIT_WAVES_PER_EU, LIT_WAVES_PER_EU))) void
 k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_triangle, float *hit_distance,
-                  uint2 *spill_base, DeviceCounters *counters, int big_chunk)
+                  uint2 *spill_base, DeviceCounters *counters, int big_chunk, int settle, uint32_t *retry_list)
 {
+    // (`settle`: the records came from k_load_working / k_physics, not from k_ray_setup: nobody has written the hit entries
+    //  of the slots whose record says "not to be cast" yet -- NaN, or 1/d not moderate: the strict loop's -- as in k_raycast_quad)
     const int nthreads = (int)st->n;
     if ((long long)blockIdx.x * 16 >= nthreads) return;
     uint32_t *work_counter = &st->work;
@@ -149,6 +151,11 @@ k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tri
                     has_ray = true;
                     active = true;
                     waiting = false;
+                } else if (settle && j == 0) {
+                    const int status = __float_as_int(r1.w);             // HIT_NAN, or HIT_RETRY: 1/d not moderate
+                    hit_triangle[slot] = status;
+                    hit_distance[slot] = 0.0f;
+                    if (status == HIT_RETRY) retry_list[atomicAdd(&st->retry, 1u)] = (uint32_t)slot;
                 }
             }
         }

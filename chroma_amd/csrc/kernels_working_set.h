@@ -18,8 +18,9 @@
 #endif
 __global__ __launch_bounds__(PHYS_BLOCK) void
 k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t n, uint32_t ncopies, uint32_t true_n, float4 *rays,
-               uint32_t *coherence, const uint32_t *order = nullptr)
+               uint32_t *coherence, const uint32_t *order = nullptr, int literal_rays = 0)
 {
+    // (`literal_rays`: ray records for k_raycast_literal -- 1/d and -o/d in place of the fused slab constants)
     // (`order`: take the photons up in this order instead of by index -- propagate_order below; ncopies == 1 then)
     // (`rays`: also the ray records of the first step -- the first launch of a call always re-normalises)
     // (`coherence`: [0] += waves whose photons share an origin and lie within a cone of 50 mrad, [1] += waves looked at:
@@ -65,7 +66,7 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
         for (uint32_t q = lane_id(); q < 4u * nsurv; q += WAVE) work[4 * (size_t)first_slot + q] = st[q];
         __builtin_amdgcn_wave_barrier();
         if (rays) {
-            if (take) make_ray_record(g, st + 4 * rnk, pos, dir, 1, lh);
+            if (take) make_ray_record(g, st + 4 * rnk, pos, dir, 1, lh, literal_rays != 0);
             __builtin_amdgcn_wave_barrier();
             for (uint32_t q = lane_id(); q < 4u * nsurv; q += WAVE) rays[4 * (size_t)first_slot + q] = st[q];
             __builtin_amdgcn_wave_barrier();
@@ -81,7 +82,7 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
             w[1] = make_float4(dir.x, dir.y, dir.z, pv.t[photon_id]);
             w[2] = make_float4(pol.x, pol.y, pol.z, pv.weights[photon_id]);
             w[3] = make_float4(__uint_as_float(flags), __uint_as_float(pv.rng_counters[photon_id]), __int_as_float(lh), __uint_as_float(photon_id));
-            if (rays) make_ray_record(g, rays + 4 * (size_t)(at - 1u), pos, dir, 1, lh);
+            if (rays) make_ray_record(g, rays + 4 * (size_t)(at - 1u), pos, dir, 1, lh, literal_rays != 0);
 #endif
             if (coherence) {
                 // against the wave's first taken lane (the lanes of a wave land in consecutive slots)
