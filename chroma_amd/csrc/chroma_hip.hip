@@ -8,9 +8,9 @@
 //   kernels_raycast_crosscheck.h  k_raycast_persistent / _wide / _coop -- cross-check walks (+ the eight-lane helpers)
 //   kernel_raycast_quad.h         k_raycast_quad -- the DEFAULT ray cast
 //   kernel_raycast_pair.h         k_raycast_pair -- cross-check walk
-//   kernel_tail_coop.h            k_tail_coop -- the last photons' remaining steps in one launch
+//   kernel_raycast_literal.h      k_raycast_literal -- the EXACT walk (mesh.h:42-118 for every ray), and its cast for the tail kernel
+//   kernel_tail_coop.h            k_tail_coop -- the last photons' remaining steps in one launch (default and exact walk)
 //   kernel_raycast_retry.h        k_raycast_retry -- the strict loop for rays the fast walks hand over
-//   kernel_raycast_literal.h      k_raycast_literal -- the EXACT walk (mesh.h:42-118 for every ray)
 //   kernel_physics.h              k_physics
 //   kernels_working_set.h         k_load_working, k_store_working
 //   kernels_photons_hits.h        photon-array kernels, hit extraction, k_finalize_hits
@@ -212,11 +212,11 @@ extern "C" hipError_t chroma_internal_malloc(chroma_ctx *ctx, void **ptr, size_t
 #include "experimental/raycast_packet.h"
 #endif
 
+#include "kernel_raycast_literal.h"
+
 #include "kernel_tail_coop.h"
 
 #include "kernel_raycast_retry.h"
-
-#include "kernel_raycast_literal.h"
 
 #include "kernel_physics.h"
 
@@ -536,12 +536,11 @@ static int launch_tail(chroma_ctx *ctx, const CallOpts &co, chroma_geometry *geo
         HIP_TRY(hipEventRecord(ctx->ev_join, ctx->aux_stream));
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[0], ctx->stream)); HIP_TRY(hipEventRecord(ev[1], ctx->stream)); }
-    if (co.counting)
-        hipLaunchKernelGGL((k_tail_coop<true>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in,
-                           rng.seed, rng.photon_id_base, nsteps, use_weights, scatter_first, ctx->coop_spill, ctx->d_counters, ho, words);
-    else
-        hipLaunchKernelGGL((k_tail_coop<false>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in,
-                           rng.seed, rng.photon_id_base, nsteps, use_weights, scatter_first, ctx->coop_spill, ctx->d_counters, ho, words);
+#define TAIL_LAUNCH(C, L) hipLaunchKernelGGL((k_tail_coop<C, L>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, pv, st, work_in, \
+                                             rng.seed, rng.photon_id_base, nsteps, use_weights, scatter_first, ctx->coop_spill, ctx->d_counters, ho, words)
+    if (co.walk == CHROMA_WALK_LITERAL) { if (co.counting) TAIL_LAUNCH(true, true); else TAIL_LAUNCH(false, true); }
+    else { if (co.counting) TAIL_LAUNCH(true, false); else TAIL_LAUNCH(false, false); }
+#undef TAIL_LAUNCH
     if (ev) HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     if (beside) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     HIP_TRY(hipGetLastError());
@@ -1568,6 +1567,7 @@ int chroma_intersect_mesh(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthrea
     uint32_t need = geom->stack_need;
     if (need > STACK_LDS + STACK_SCRATCH)
         return set_error(CHROMA_ERR_STACK, "BVH needs %u traversal stack entries, more than the %d supported", need, STACK_LDS + STACK_SCRATCH);
+    std::lock_guard<std::mutex> call_lock(ctx->call_mu);          // (the fast path uses the context's queues and ray records, as a propagate call does)
     if (geom->view.wnodes && geom->wide_stack_need <= COOP_STACK + COOP_SPILL && ctx->wide_walk != CHROMA_WALK_REFERENCE &&
         ctx->wide_walk != CHROMA_WALK_LITERAL && ctx->wide_walk != CHROMA_WALK_LITERAL_LANE)
         return distance_to_mesh_fast(ctx, geom, nthreads, d_origin, d_direction, d_last_hit, d_distance, d_triangle);
@@ -1844,7 +1844,7 @@ static int propagate_impl(chroma_ctx *ctx, chroma_geometry *geom, const chroma_p
         bool done = false, tail_done = false;
         const long long few = (long long)PROP_BLOCK * 16 * 8;
         const bool fused_tail = co.fused_tail && (co.walk == CHROMA_WALK_COOP || co.walk == CHROMA_WALK_QUAD ||
-                                                    co.walk == CHROMA_WALK_PAIR);    // (the cross-check walks keep per-step launches)
+                                                    co.walk == CHROMA_WALK_PAIR || co.walk == CHROMA_WALK_LITERAL);    // (the cross-check walks keep per-step launches)
         int tail_step = -1;                  // the step at which the fused tail was launched
         while (step < max_steps && !done) {
             if (fused_tail && n_upper < few) {

@@ -311,3 +311,97 @@ k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tri
     }
 #endif
 }
+
+// ---- the same walk for ONE ray per group of 8 lanes, on its own: the cast of the tail kernel under the exact walk ------------
+// k_tail_coop<.., LITERAL> finishes the last (< 8192) photons of a call in one launch, a group of 8 lanes per photon; its ray cast
+// is this function: the chunk loop of k_raycast_literal without the scheduling against other rays (a group with a triangle to
+// test tests it at once).  The two quads of a group do the same work on the same values (lane j and lane j + 4 take the same
+// child): the tail is a chain of dependent fetches, not a throughput problem.  Returns the record index, -1, or HIT_RETRY for
+// a ray whose 1/d is not moderate (the caller's strict loop takes it).
+template <bool COUNT>
+__device__ inline int literal_cast_group8(const GeoView &g, v3 origin, v3 direction, int last_hit, bool on, float &min_distance,
+                                          uint32_t *stack, uint32_t *spill, unsigned j8, LaneCounters &cnt)
+{
+    const unsigned j = j8 & 3u;
+    const uint32_t jbit = 1u << j, below = jbit - 1u;
+    const float ws = g.world_scale, wox = g.world_origin[0], woy = g.world_origin[1], woz = g.world_origin[2];
+    int triangle_index = -1;
+    min_distance = -1.0f;
+    v3 noid = mk3(0.f, 0.f, 0.f), inv_dir = mk3(0.f, 0.f, 1.f);
+    bool active = false;
+    if (on) {
+        noid = (-origin) / direction;
+        inv_dir = 1.0f / direction;
+        const bool moderate = cm_fabsf(inv_dir.x) < 1e30f && cm_fabsf(inv_dir.y) < 1e30f && cm_fabsf(inv_dir.z) < 1e30f &&
+                              cm_fabsf(noid.x) < 1e30f && cm_fabsf(noid.y) < 1e30f && cm_fabsf(noid.z) < 1e30f;
+        if (!moderate) triangle_index = HIT_RETRY; else active = true;
+    }
+    uint32_t cur = 0, end = 1;           // the root, tested like any other node (mesh.h:55)
+    int sp = 0;
+    while (__any(active)) {
+        if (active && cur >= end) {
+            if (sp == 0) {
+                active = false;
+            } else {
+                sp--;
+                const uint32_t w = (sp < LIT_STACK) ? stack[sp] : spill[sp - LIT_STACK];
+                cur = w & ~CHROMA_NCHILD_MASK;
+                end = cur + (w >> CHROMA_CHILD_BITS);
+            }
+        }
+        if (active) {
+            const uint32_t idx = cur + j;
+            const bool valid = idx < end;
+            const uint4 nd = g.nodes[valid ? idx : end - 1u];
+            if (COUNT && j8 == 0 && end != 1u) cnt.nodes += min(4u, end - cur);
+            cur += 4u;
+            const float tmin = box_tmin_exact(nd, ws, wox, woy, woz, inv_dir, noid);
+            const bool pass = valid && node_passes(tmin, min_distance);
+            const bool leaf = (nd.w >> CHROMA_CHILD_BITS) == 0u;
+            const bool is_tri = pass && leaf && (int)(nd.w & ~CHROMA_NCHILD_MASK) != last_hit;
+            const bool is_inner = pass && !leaf;
+            const uint32_t qm = quad_or_u32((is_inner ? (jbit << 4) : 0u) | (is_tri ? jbit : 0u));
+            uint32_t acc = qm >> 4;                      // the inner children to push: all that pass, unless a triangle intervenes
+            if (qm & 0xFu) {
+                bool hit = false;
+                float distance = 0.0f;
+                if (is_tri) {
+                    const float4 *tp = g.tri + TRI_STRIDE * (size_t)(nd.w & ~CHROMA_NCHILD_MASK);
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    hit = intersect_triangle(origin, direction, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), distance);
+                }
+                const uint32_t hm = quad_or_u32(hit ? jbit : 0u);
+                const float t0 = quad_bcast_f32<0>(tmin), t1 = quad_bcast_f32<1>(tmin), t2 = quad_bcast_f32<2>(tmin), t3 = quad_bcast_f32<3>(tmin);
+                const float d0 = quad_bcast_f32<0>(distance), d1 = quad_bcast_f32<1>(distance), d2 = quad_bcast_f32<2>(distance), d3 = quad_bcast_f32<3>(distance);
+                float m = min_distance;
+                uint32_t win = 4u, ntested = 0u;
+                acc = 0u;
+#define LIT_REPLAY(K, TK, DK)                                                                                          \
+                if ((qm & (0x11u << K)) && node_passes(TK, m)) {                                                       \
+                    if (qm & (1u << K)) {                                                                              \
+                        ntested++;                                                                                     \
+                        if ((hm & (1u << K)) && (m < 0.0f || DK < m)) { m = DK; win = K; }          /* mesh.h:88 */     \
+                    } else {                                                                                           \
+                        acc |= 1u << K;                                                                                \
+                    }                                                                                                  \
+                }
+                LIT_REPLAY(0, t0, d0) LIT_REPLAY(1, t1, d1) LIT_REPLAY(2, t2, d2) LIT_REPLAY(3, t3, d3)
+#undef LIT_REPLAY
+                if (COUNT && j8 == 0) cnt.tris += ntested;
+                const uint32_t wchild = quad_max_u32(j == win ? (nd.w & ~CHROMA_NCHILD_MASK) + 1u : 0u);
+                if (win != 4u) { triangle_index = (int)wchild - 1; min_distance = m; }
+            }
+            if (acc) {
+                const int pos = sp + (int)__popc(acc & below);
+                if ((acc & jbit) && j8 < 4u) {
+                    if (pos < LIT_STACK) stack[pos] = nd.w;
+                    else if (pos < LIT_STACK + LIT_SPILL) { spill[pos - LIT_STACK] = nd.w; if (COUNT) cnt.spills++; }
+                }
+                sp += (int)__popc(acc);
+                if (sp > LIT_STACK + LIT_SPILL) { if (j8 == 0) cnt.overflows++; sp = LIT_STACK + LIT_SPILL; }
+            }
+            __builtin_amdgcn_wave_barrier();      // (scheduling fence: lanes 0..3 wrote stack words every lane of the group will read)
+        }
+    }
+    return triangle_index;
+}

@@ -126,7 +126,7 @@ __device__ inline int coop_cast(const GeoView &g, v3 origin, v3 direction, int l
     return triangle_index;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool LITERAL = false>
 __global__ __launch_bounds__(PROP_BLOCK) void
 k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const float4 *work_in,
             uint64_t seed, uint64_t id_base, int max_steps, int use_weights, int scatter_first, uint2 *spill_base,
@@ -189,12 +189,16 @@ k_tail_coop(GeoView g, PhotonView pv, const StepState *st, const float4 *work_in
             } else if (COUNT && j == 0) cnt.steps++;
         }
         float distance;
-        int record = coop_cast<COUNT>(g, p.position, p.direction, last_hit_dev, stepping, distance, stack_n, stack_t, pending,
-                                      spill, j, gshift, below, cnt);
+        // (LITERAL: the exact walk's cast -- chroma/cuda/mesh.h:42-118 itself, kernel_raycast_literal.h; its stack words live
+        //  where the wide walk keeps its (node, distance) entries)
+        int record = LITERAL ? literal_cast_group8<COUNT>(g, p.position, p.direction, last_hit_dev, stepping, distance, stack_n,
+                                                          (uint32_t *)spill, j, cnt)
+                             : coop_cast<COUNT>(g, p.position, p.direction, last_hit_dev, stepping, distance, stack_n, stack_t, pending,
+                                                spill, j, gshift, below, cnt);
         // the reference's own walk for the rays the wide walk cannot take, and for winners that are not
         // regular (record_hit_is_regular): first lane of the group, then shared
         bool general = stepping && record == HIT_RETRY;
-        if (stepping && record >= 0) {
+        if (!LITERAL && stepping && record >= 0) {
             const float4 *t = g.tri + TRI_STRIDE * (size_t)record;
             general = !record_hit_is_regular(g, t[0], t[1], t[2], p.position, p.direction, distance);
         }
