@@ -32,6 +32,10 @@ def test_struct_sizes_match_the_header():
     assert ctypes.sizeof(_lib.Rng) == 16
     assert ctypes.sizeof(_lib.PropagateStats) == 136         # (+ physics_*, packet_*, reordered: round 3)
     assert ctypes.sizeof(_lib.GeometryDesc) % 8 == 0
+    # round 4: what one call does (chroma_propagate_options: 12 int32) and where its hits go (chroma_hits_request: two
+    # uint32, four pointers, the count -- padded to a multiple of 8)
+    assert ctypes.sizeof(_lib.PropagateOptions) == 48
+    assert ctypes.sizeof(_lib.HitsRequest) == 48 and _lib.HitsRequest.nhits.offset == 40 and _lib.HitsRequest.dst.offset == 8
 
 
 def test_missing_library_fails_loudly(monkeypatch):
