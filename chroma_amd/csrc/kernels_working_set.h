@@ -23,19 +23,26 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
     // (`literal_rays`: ray records for k_raycast_literal -- 1/d and -o/d in place of the fused slab constants)
     // (`order`: take the photons up in this order instead of by index -- propagate_order below; ncopies == 1 then)
     // (`rays`: also the ray records of the first step -- the first launch of a call always re-normalises)
+    // (`order` and `coherence` serve the experiments of csrc/experimental/ only: the product passes NULL, and their code is not built)
     // (`coherence`: [0] += waves whose photons share an origin and lie within a cone of 50 mrad, [1] += waves looked at:
     //  what decides between k_raycast_packet and k_raycast_quad for the first step.  A heuristic: it steers speed only.)
     __shared__ uint32_t s_counts[PHYS_BLOCK / WAVE + 1];
 #if LOAD_STAGE_LDS
     __shared__ float4 s_stage[PHYS_BLOCK / WAVE][WAVE * 4];
 #endif
+#if CHROMA_EXPERIMENTAL
     uint32_t coh_yes = 0, coh_all = 0;
+#endif
     for (uint64_t block_base = (uint64_t)blockIdx.x * PHYS_BLOCK; block_base < n; block_base += (uint64_t)gridDim.x * PHYS_BLOCK) {
         uint64_t j = block_base + threadIdx.x;
         bool take = false;
         uint32_t photon_id = 0, flags = 0;
         if (j < n) {
+#if CHROMA_EXPERIMENTAL
             photon_id = order ? order[j] : (uint32_t)(j / ncopies) + (uint32_t)(j % ncopies) * true_n;
+#else
+            photon_id = (uint32_t)(j / ncopies) + (uint32_t)(j % ncopies) * true_n;
+#endif
             flags = pv.flags[photon_id];
             take = (flags & CHROMA_TERMINAL_MASK) == 0;
         }
@@ -84,6 +91,7 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
             w[3] = make_float4(__uint_as_float(flags), __uint_as_float(pv.rng_counters[photon_id]), __int_as_float(lh), __uint_as_float(photon_id));
             if (rays) make_ray_record(g, rays + 4 * (size_t)(at - 1u), pos, dir, 1, lh, literal_rays != 0);
 #endif
+#if CHROMA_EXPERIMENTAL
             if (coherence) {
                 // against the wave's first taken lane (the lanes of a wave land in consecutive slots)
                 const unsigned long long m = __ballot(true);
@@ -96,12 +104,15 @@ k_load_working(GeoView g, PhotonView pv, uint32_t *queue, float4 *work, uint64_t
                 const unsigned long long ok = __ballot(near);
                 if ((int)lane_id() == first && __popcll(m) >= 32) { coh_all++; coh_yes += (ok == m) ? 1u : 0u; }
             }
+#endif
         }
         __syncthreads();
     }
+#if CHROMA_EXPERIMENTAL
     if (coherence) {
         if (coh_all) { atomicAdd(&coherence[1], coh_all); if (coh_yes) atomicAdd(&coherence[0], coh_yes); }
     }
+#endif
 }
 
 // the photons still alive when the call ends go back to the caller's arrays

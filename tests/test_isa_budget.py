@@ -54,7 +54,7 @@ def test_every_kernel_of_the_path_is_in_the_table(isa_table):
     # the exact walk: full occupancy, its state in registers
     k = isa_table['k_raycast_literal<false>']
     assert k['scratch'] == 0 and k['waves'] == 8 and k['vgpr'] <= 64 and k['lds'] == 16 * 33 * 4, k
-    for name in ('k_physics<false>', 'k_physics<true>', 'k_tail_coop<false>', 'k_finalize_hits', 'k_propagate<24, false>', 'k_raycast_retry<false, false>', 'k_raycast_retry<false, true>', 'k_raycast_wide<false>',
+    for name in ('k_physics<false>', 'k_physics<true>', 'k_tail_coop<false, false>', 'k_tail_coop<false, true>', 'k_finalize_hits', 'k_propagate<24, false>', 'k_raycast_retry<false, false>', 'k_raycast_retry<false, true>', 'k_raycast_wide<false>',
                  'k_raycast_persistent<false>', 'k_distance_to_mesh<24, false>', 'k_copy_hits', 'k_daq_reset', 'k_daq_convert'):
         assert name in isa_table, name
     assert isa_table['k_physics<true>']['waves'] >= 4
