@@ -121,6 +121,7 @@ struct chroma_ctx {
     int pair_waves = 256 * 20;             // grid of k_raycast_pair (32 rays per wave)
     uint2 *coop_spill = nullptr;           // [coop_waves][8][COOP_SPILL]
     int ray_chunk = 256, coop_chunk = 64;  // rays a persistent wave takes from the queue per atomic (big batches)
+    int claim_static = 5 | 8 << 4;                  // eighths of a wave's share of a launch's rays that it takes without the counter (k_raycast_quad; CHROMA_CLAIM_STATIC)
     int fused_tail = 1;                    // 0 (CHROMA_TAIL=split): the last photons also take one launch set per step
     int split_tail = 1;                    // 0 (CHROMA_TAIL=fused): chroma_propagate launches the fused kernel only, as the reference does
     int autosort_mode = 0;                 // the order a large call takes its photons up in: 0 as they come (default: the index sort + gather cost more than they gain, profiles/r03/ab_autosort.txt), 1 by direction cell, 2 decided by a probe (propagate_order)
@@ -389,12 +390,12 @@ static int launch_split_step(chroma_ctx *ctx, const CallOpts &co, chroma_geometr
             const unsigned rblocks = (unsigned)std::min<long long>((n_upper + PROP_BLOCK - 1) / PROP_BLOCK, 8 * 256);
             if (co.counting) {
                 hipLaunchKernelGGL((k_raycast_literal<true>), dim3(lwaves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
-                                   ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, chained_lit ? 1 : 0, ctx->retry_list);
+                                   ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, chained_lit ? 1 : 0, ctx->retry_list, ctx->claim_static);
                 hipLaunchKernelGGL((k_raycast_retry<true>), dim3(rblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
                                    ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
             } else {
                 hipLaunchKernelGGL((k_raycast_literal<false>), dim3(lwaves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
-                                   ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, chained_lit ? 1 : 0, ctx->retry_list);
+                                   ctx->hit_triangle, ctx->hit_distance, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, chained_lit ? 1 : 0, ctx->retry_list, ctx->claim_static);
                 hipLaunchKernelGGL((k_raycast_retry<false>), dim3(rblocks), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, st,
                                    ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->d_counters);
             }
@@ -465,7 +466,7 @@ static int launch_split_step(chroma_ctx *ctx, const CallOpts &co, chroma_geometr
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
         else if (quad)                                                                                                 \
             hipLaunchKernelGGL((k_raycast_quad<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
-                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, settle, skip_quad); \
+                               ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, settle, skip_quad, ctx->claim_static); \
         else if (coop)                                                                                                 \
             hipLaunchKernelGGL((k_raycast_coop<COUNT>), grid, block, 0, ctx->stream, geom->view, ctx->rays, 0, st,      \
                                ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk); \
@@ -811,6 +812,7 @@ int chroma_init(int device, chroma_ctx **out)
 #endif
         if (const char *e = getenv("CHROMA_RAY_CHUNK")) ctx->ray_chunk = std::max(64, atoi(e));
         if (const char *e = getenv("CHROMA_COOP_CHUNK")) ctx->coop_chunk = std::max(8, atoi(e));
+        if (const char *e = getenv("CHROMA_CLAIM_STATIC")) { int big = 0, small = 0; if (sscanf(e, "%d:%d", &big, &small) < 2) small = big; ctx->claim_static = std::min(8, std::max(0, big)) | std::min(8, std::max(0, small)) << 4; }
         if (const char *e = getenv("CHROMA_TAIL")) {      // coop (default) | split | fused (the lane-per-photon k_propagate)
             ctx->split_tail = (strcmp(e, "fused") != 0);
             ctx->fused_tail = (strcmp(e, "split") != 0 && strcmp(e, "fused") != 0);
@@ -1595,10 +1597,10 @@ static int distance_to_mesh_fast(chroma_ctx *ctx, chroma_geometry *geom, int32_t
     const unsigned waves = (unsigned)std::min<long long>(((long long)n + 15) / 16, (long long)ctx->quad_waves);
     if (ctx->counting)
         hipLaunchKernelGGL((k_raycast_quad<true>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, 0, st,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, 0);
+                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, 0, nullptr, ctx->claim_static);
     else
         hipLaunchKernelGGL((k_raycast_quad<false>), dim3(waves), dim3(PROP_BLOCK), 0, ctx->stream, geom->view, ctx->rays, 0, st,
-                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, 0);
+                           ctx->hit_triangle, ctx->hit_distance, ctx->retry_list, ctx->coop_spill, ctx->d_counters, ctx->coop_chunk, 0, nullptr, ctx->claim_static);
     hipLaunchKernelGGL(k_distance_finish, dim3(blocks), dim3(256), 0, ctx->stream, geom->view, (int)n, ctx->rays, ctx->hit_triangle,
                        ctx->hit_distance, d_distance, d_triangle, ctx->retry_list, st);
     if (ctx->counting)

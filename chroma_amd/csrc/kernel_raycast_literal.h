@@ -81,7 +81,7 @@ __device__ inline float box_tmin_exact(uint4 nd, float ws, float wox, float woy,
 template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(LIT_WAVES_PER_EU, LIT_WAVES_PER_EU))) void
 k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_triangle, float *hit_distance,
-                  uint2 *spill_base, DeviceCounters *counters, int big_chunk, int settle, uint32_t *retry_list)
+                  uint2 *spill_base, DeviceCounters *counters, int big_chunk, int settle, uint32_t *retry_list, int static_eighths = 0)
 {
     // (`settle`: the records came from k_load_working / k_physics, not from k_ray_setup: nobody has written the hit entries
     //  of the slots whose record says "not to be cast" yet -- NaN, or 1/d not moderate: the strict loop's -- as in k_raycast_quad)
@@ -89,6 +89,7 @@ k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tri
     if ((long long)blockIdx.x * 16 >= nthreads) return;
     uint32_t *work_counter = &st->work;
     const int chunk = ((long long)nthreads > 4ll * big_chunk * (long long)gridDim.x) ? big_chunk : 16;
+    WorkClaim wc(nthreads, chunk, static_eighths);          // (kernel_step_control.h: most chunks without the counter)
     static_assert(PROP_BLOCK == WAVE, "one wave per workgroup");
     __shared__ uint32_t s_lds[16 * LIT_STRIDE];
     const unsigned lane = lane_id();
@@ -123,10 +124,7 @@ k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tri
         bool more = !exhausted || loc_next < loc_end;
         if (more && (n_idle >= LIT_REFILL_MIN || n_idle == 16)) {
             if (loc_next >= loc_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work_counter, (uint32_t)chunk);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base + (uint32_t)chunk >= (uint32_t)nthreads) exhausted = true;
+                const uint32_t base = wc.next(work_counter, lane, exhausted);
                 loc_next = min(base, (uint32_t)nthreads);
                 loc_end = min(base + (uint32_t)chunk, (uint32_t)nthreads);
             }

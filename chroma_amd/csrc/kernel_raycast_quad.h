@@ -92,7 +92,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(PROP_BLOCK) __attribute__((amdgpu_waves_per_eu(QUAD_WAVES_PER_EU, QUAD_WAVES_PER_EU))) void
 k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
                int32_t *hit_triangle, float *hit_distance, uint32_t *retry_list, uint2 *spill_base, DeviceCounters *counters,
-               int big_chunk, int settle, const uint32_t *skip = nullptr)
+               int big_chunk, int settle, const uint32_t *skip = nullptr, int static_eighths = 0)
 {
     // (`settle`: nobody has written the hit entries of the slots whose ray record says "not to be cast" yet)
     // (`skip`: the step has been given to k_raycast_packet, launched before this kernel)
@@ -101,6 +101,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
     if ((long long)blockIdx.x * 16 >= nthreads) return;
     uint32_t *work_counter = &st->work, *retry_counter = &st->retry;
     const int chunk = ((long long)nthreads > 4ll * big_chunk * (long long)gridDim.x) ? big_chunk : 16;
+    WorkClaim wc(nthreads, chunk, static_eighths);
     static_assert(PROP_BLOCK == WAVE, "one wave per workgroup");
     static_assert((QUAD_PENDING & (QUAD_PENDING - 1)) == 0 && QUAD_FLUSH - 1 + 8 <= QUAD_PENDING && QUAD_KEEP < QUAD_FLUSH, "ring of postponed triangles");
     __shared__ uint32_t s_lds[16 * QUAD_STRIDE];
@@ -151,10 +152,7 @@ k_raycast_quad(GeoView g, const float4 *rays, int first_photon, StepState *st,
         bool more = !exhausted || loc_next < loc_end;
         if (more && (n_idle >= QUAD_REFILL_MIN || n_idle == 16)) {
             if (loc_next >= loc_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work_counter, (uint32_t)chunk);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);       // (wave-uniform from here: scalar registers)
-                if (base + (uint32_t)chunk >= (uint32_t)nthreads) exhausted = true;
+                const uint32_t base = wc.next(work_counter, lane, exhausted);        // (wave-uniform: scalar registers)
                 loc_next = min(base, (uint32_t)nthreads);
                 loc_end = min(base + (uint32_t)chunk, (uint32_t)nthreads);
             }

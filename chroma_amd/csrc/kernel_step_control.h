@@ -102,3 +102,41 @@ k_ray_setup(GeoView g, const float4 *work, const StepState *st, float4 *rays,
         }
     }
 }
+
+// ---- how a persistent ray-cast wave takes its rays (k_raycast_quad, k_raycast_literal) ---------------------------------------
+// Most of a launch's rays are dealt out WITHOUT the work counter: the atomics of all waves on one word run at ~1e8 per second
+// (every XCD's L2 hands them on to the memory side), and at 16-64 short rays per claim that rate IS the launch -- C5's 6-node
+// tree: 0.19 ns per ray at any size; a small launch: two atomics per wave, 0.1 ms (profiles/r04/ab_static_claims.txt).
+// Wave b of the W that take part owns the chunks b, b + W, b + 2W, ... of the first `eighths` / 8 of its share -- at least
+// one -- and only the rest, what evens the waves out, goes through the counter; a launch of at most W chunks touches no counter
+// at all.  `eighths` holds two shares: bits 0-3 for launches of big chunks (5: with 7 C3's big launches wait for their slowest
+// waves, +5 %), bits 4-7 for the small ones (8).  0: every chunk through the counter (rounds 1-3).
+struct WorkClaim {
+    uint32_t n, chunk, left, stride, next_static, dyn_base;
+    bool no_dynamic;
+    __device__ WorkClaim(int nthreads, int chunk_, int eighths)
+    {
+        n = (uint32_t)nthreads; chunk = (uint32_t)chunk_;
+        const uint32_t e = (uint32_t)((chunk_ == 16) ? (eighths >> 4) : (eighths & 15));
+        const uint32_t nwaves = min((uint32_t)gridDim.x, (n + 15u) / 16u), nchunks = (n + chunk - 1u) / chunk;
+        left = e ? max(nchunks / nwaves * e / 8u, 1u) : 0u;
+        stride = chunk * nwaves;
+        dyn_base = left * stride;
+        no_dynamic = e && dyn_base >= n;
+        next_static = (uint32_t)blockIdx.x * chunk;
+    }
+    // first ray of the wave's next chunk (the caller clamps [base, base + chunk) to n); `exhausted`: there is none after it
+    __device__ uint32_t next(uint32_t *counter, unsigned lane, bool &exhausted)
+    {
+        uint32_t base = 0;
+        if (left) {
+            base = next_static; next_static += stride; left--;
+            if (!left && no_dynamic) exhausted = true;
+        } else {
+            if (lane == 0) base = atomicAdd(counter, chunk);
+            base = dyn_base + (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + chunk >= n) exhausted = true;
+        }
+        return base;
+    }
+};

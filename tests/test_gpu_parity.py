@@ -715,3 +715,52 @@ def test_kernels_by_name_and_the_chroma_import_name(oracle_mod, tiny_geometry):
         assert (dist.get() > 1000).all()
     finally:
         ctx.pop()
+
+
+@pytest.mark.gpu
+def test_every_ray_of_a_launch_is_cast_once_at_the_sizes_where_the_work_claims_change(gpu, oracle_mod, tiny_geometry, tiny_packed):
+    """A persistent ray-cast wave owns part of its rays by position and takes the rest from a counter (WorkClaim,
+    csrc/kernel_step_control.h); what it owns depends on the launch size against the grid (6144 waves of 16 rays) and on the
+    claim size (16 rays, 64 above 4 * 64 * 6144).  One pool of rays checked against the oracle once; then launches of every
+    size around those boundaries, for the default and the exact walk, must return the pool's first n results -- every ray
+    cast, none twice (a ray cast by nobody keeps the NaN its slot was filled with)."""
+    from chroma_amd.gpu.tools import to_gpu, GPUArray
+    from chroma_amd import _lib
+    ctx = gpu.get_context()
+    waves = 6144
+    sizes = [1, 15, 16, 17, 1000, 16 * waves - 1, 16 * waves, 16 * waves + 1, 16 * waves + 16, 2 * 16 * waves + 5, 300001,
+             4 * 64 * waves, 4 * 64 * waves + 1, 4 * 64 * waves + 64 * waves + 77]
+    nmax = max(sizes)
+    rng = np.random.default_rng(41)
+    o = rng.uniform(-1500, 1500, (nmax, 3)).astype(np.float32)
+    d = rng.normal(size=(nmax, 3)).astype(np.float32)
+    gg = gpu.GPUDetector(tiny_geometry)
+    d_o, d_d = to_gpu(o.reshape(-1), ctx), to_gpu(d.reshape(-1), ctx)
+    check = np.unique(np.concatenate([np.arange(0, 40000), np.arange(nmax - 40000, nmax), rng.integers(0, nmax, 40000),
+                                      np.concatenate([np.arange(max(0, s - 40), min(nmax, s + 40)) for s in sizes])]))
+    wd, wt, _ = oracle_mod.distance_to_mesh(tiny_packed, o[check], d[check])
+    full = None
+    for n in sorted(sizes, reverse=True):
+        dist = GPUArray(n, np.float32, ctx).fill(np.float32(np.nan))
+        tri = GPUArray(n, np.int32, ctx).fill(np.int32(-7))
+        _lib.check(ctx._lib.chroma_distance_to_mesh(ctx.handle, gg.handle, n, d_o.ptr, d_d.ptr, dist.ptr, tri.ptr))
+        gd, gt = dist.get(), tri.get()
+        if full is None:
+            full = (gd, gt)
+            assert np.array_equal(gt[check], wt)
+            assert np.array_equal(gd[check].view(np.uint32), wd.view(np.uint32))
+            assert (gt != -7).all()
+        else:
+            assert np.array_equal(gt, full[1][:n]), '%d rays' % n
+            assert np.array_equal(gd.view(np.uint32), full[0][:n].view(np.uint32)), '%d rays' % n
+    # the exact walk's kernel takes its rays the same way: one step of n photons, exact against default (equal on this geometry
+    # for random photons: the walks differ on aimed rays of one class only, tests/test_gpu_literal.py)
+    for n in (16 * waves - 1, 16 * waves + 1, 2 * 16 * waves + 5, 4 * 64 * waves + 1):
+        ph = oracle_mod.generate_bomb(n, seed=n)
+        ends = []
+        for exact in (False, True):
+            gp = gpu.GPUPhotons(ph)
+            gp.propagate(gg, gpu.get_rng_states(64, seed=3), max_steps=1, exact=exact)      # (the same draws for both)
+            ends.append(gp.get())
+        assert_bit_exact(ends[0], ends[1], 'one step of %d photons, exact walk against default' % n)
+        assert (ends[1].last_hit_triangles >= 0).mean() > 0.5
