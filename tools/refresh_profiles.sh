@@ -25,6 +25,7 @@ export CHROMA_BENCH_NO_EXACT=1      # (the profiles are of the default walk: no 
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_c3 -- python3 bench.py --no-cpu-baseline > $out/rocprof_c3.json 2> $out/rocprof_c3.log || exit 1
 python tools/prof_summary.py $out/rocprof_c3 $out/rocprof_c3_default_summary.txt bench.py
+python tools/launch_profile.py $out/rocprof_c3 $out/launch_profile_c3.txt > /dev/null      # (per-launch durations of the last call of the same run)
 rm -rf $out/rocprof_c3
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 5 300 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $out/pmc_$c.stdout 2> $out/pmc_$c.stderr || exit 1
