@@ -38,6 +38,9 @@
 #ifndef LIT_TRI_MIN
 #define LIT_TRI_MIN 8         // run the triangle pass once this many of the 16 quads wait for it
 #endif
+#ifndef LIT_TRI_END_HALF
+#define LIT_TRI_END_HALF 1    // with no ray left to take, the triangle pass runs once half of the wave's remaining rays wait for it
+#endif
 #ifndef LIT_REFILL_MIN
 #define LIT_REFILL_MIN 4      // refill once this many of the 16 rays are done
 #endif
@@ -165,6 +168,10 @@ k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tri
         // ---- node phase: every quad that is not waiting for its triangles scans four children of its range
         more = !exhausted || loc_next < loc_end;
         const int stop_at = more ? max(0, (int)__popcll(__ballot(active && !waiting) & 0x1111111111111111ull) - (int)LIT_REFILL_MIN) : 0;
+        // (no ray left to take: the wave's rays are fewer every pass, and a quad that waits for LIT_TRI_MIN of them waits for
+        //  all the others -- the triangle pass then runs once half of the rays that are left wait for it, the share LIT_TRI_MIN
+        //  is of a full wave; what a small launch takes is its longest ray)
+        const int tri_min = (more || !LIT_TRI_END_HALF) ? (int)LIT_TRI_MIN : max(1, min((int)LIT_TRI_MIN, ((int)__popcll(__ballot(has_ray) & 0x1111111111111111ull) + 1) / 2));
         do {
 #if LIT_DIAG
             if (COUNT) { diag_iters++; diag_running += (unsigned)__popcll(__ballot(active && !waiting) & 0x1111111111111111ull); }
@@ -225,7 +232,7 @@ k_raycast_literal(GeoView g, const float4 *rays, StepState *st, int32_t *hit_tri
                     w_qm = qm;
                 }
             }
-        } while ((int)__popcll(__ballot(waiting) & 0x1111111111111111ull) < LIT_TRI_MIN &&
+        } while ((int)__popcll(__ballot(waiting) & 0x1111111111111111ull) < tri_min &&
                  (int)__popcll(__ballot(active && !waiting) & 0x1111111111111111ull) > stop_at);
         __builtin_amdgcn_s_setprio(0);
 
