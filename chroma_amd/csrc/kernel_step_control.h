@@ -119,7 +119,9 @@ struct WorkClaim {
         n = (uint32_t)nthreads; chunk = (uint32_t)chunk_;
         const uint32_t e = (uint32_t)((chunk_ == 16) ? (eighths >> 4) : (eighths & 15));
         const uint32_t nwaves = min((uint32_t)gridDim.x, (n + 15u) / 16u), nchunks = (n + chunk - 1u) / chunk;
-        left = e ? max(nchunks / nwaves * e / 8u, 1u) : 0u;
+        // (a share of 8/8 is the whole launch: every chunk owned, the last round of chunks by the first waves only -- a wave
+        //  that must ask the counter just to learn that nothing is left costs the launch 6144 atomics, 70 us)
+        left = e == 8u ? (nchunks + nwaves - 1u) / nwaves : e ? max(nchunks / nwaves * e / 8u, 1u) : 0u;
         stride = chunk * nwaves;
         dyn_base = left * stride;
         no_dynamic = e && dyn_base >= n;

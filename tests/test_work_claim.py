@@ -73,6 +73,7 @@ int main()
                 const int e = chunk == 16 ? small : big;
                 const long long nchunks = (n + chunk - 1) / chunk;
                 if (e && nchunks <= (long long)waves.size() && n_atomics) { printf("counter touched: n %%lld grid %%u eighths %%#x\n", n, grid, eighths); return 1; }
+                if (e == 8 && n_atomics) { printf("a full share must not touch the counter: n %%lld grid %%u\n", n, grid); return 1; }
                 if (!e && n_atomics < (unsigned long long)nchunks) { printf("eighths 0 must claim every chunk through the counter\n"); return 1; }
                 cases++;
             }
