@@ -199,6 +199,49 @@ def test_c4_one_shard_of_the_billion_photon_job(gpu, c3):
     assert 0.03 < nhits / 1.25e8 < 0.15
 
 
+def _sharded_job(gpu, cfg, total, world_size):
+    """The job bench.py --gpus N runs, with the N ranks taking their turns on ONE GPU: rank r propagates the photons of
+    dist.shard_range(total, r, N) with their global ids, and what chroma_allreduce_hits does across ranks -- hit counts summed,
+    earliest-time bit patterns reduced with MIN -- is done here on the host.  Returns (counts, earliest bits, seconds spent
+    in the propagate calls)."""
+    import time
+    from chroma_amd import dist, _lib
+    counts = np.zeros(cfg.gg.nchannels, np.uint64)
+    earliest = np.full(cfg.gg.nchannels, 0x7f800000, np.uint32)
+    seconds = 0.0
+    for rank in range(world_size):
+        begin, end = dist.shard_range(total, rank, world_size)
+        gp = gpu.generate_bomb(end - begin, ENGINE_SEED, id_base=begin, wavelength_lo=400.0, wavelength_hi=0.0)
+        gpu.get_context().synchronize()
+        t0 = time.perf_counter()
+        gp.propagate(cfg.gg, _lib.Rng(ENGINE_SEED, begin), max_steps=100)
+        c, e = gp.channel_hits(cfg.gg)
+        c, e = c.get(), e.get()
+        seconds += time.perf_counter() - t0
+        counts += c
+        earliest = np.minimum(earliest, e)
+        del gp
+        gc.collect()
+    return counts, earliest, seconds
+
+
+def test_c4_the_whole_billion_photon_job_does_not_depend_on_the_sharding(gpu, c3):
+    """BASELINE.json configs[3] (C4) in full on one GPU: 1e9 photons as the EIGHT shards of the 8-GPU job, one after the
+    other, reduced as the ranks would reduce them -- and the same billion photons as FIVE shards of 2e8.  A photon's random
+    stream is keyed by its global id and photons do not interact, so the reduced per-channel arrays must be the same bits
+    whatever the number of ranks: that is the whole correctness argument of the multi-GPU path, checked
+    here at the job's real size.  (What this cannot show is RCCL moving the 230 KB between GPUs: tests/test_gpu_comm.py,
+    tests/test_dist_cpu.py.)"""
+    total = 1_000_000_000
+    c8, e8, s8 = _sharded_job(gpu, c3, total, 8)
+    print('C4 on one GPU: 8 shards of 1.25e8 photons in %.2f s = %.3g photons/s' % (s8, total / s8))
+    assert 0.03 < int(c8.sum()) / total < 0.15
+    assert (e8[c8 > 0] < 0x7f800000).all() and (e8[c8 == 0] == 0x7f800000).all()
+    c5, e5, s5 = _sharded_job(gpu, c3, total, 5)
+    assert np.array_equal(c8, c5), 'per-channel hit counts depend on the sharding'
+    assert np.array_equal(e8, e5), 'earliest hit times depend on the sharding'
+
+
 # ---- C2: demo.detector(), 10 055 PMTs, 59 M triangles (configs[1]) -----------------------------------------
 def test_c2_one_million_photons_match_the_oracle(gpu, oracle_mod, c2):
     gp, got, stats, ostats = oracle_parity(gpu, oracle_mod, c2, 1_000_000, 'C2 demo.detector(), 1e6 photons')
