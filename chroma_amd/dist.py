@@ -7,7 +7,9 @@ there is no data-path collective; the only exchange is the final PMT-hit reducti
 ordering chroma/cuda/daq.cu:5-20 relies on); for a DAQ acquisition over sharded photons also the
 integer charge (sum) and the channel histories (bitwise OR), ``allreduce_daq_channels``.  torch.distributed supplies the transport
 (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).  Because a photon's
-random stream is keyed by its GLOBAL id, results do not depend on the number of ranks.
+random stream is keyed by its GLOBAL id, its history does not depend on the number of ranks (its last bits can, for the
+stragglers of a batch: the reference stops re-normalising dir / pol once fewer than 8192 photons of a batch are alive,
+chroma/gpu/photon.py:227-230 -- a rank's result is the reference's for that rank's batch).
 """
 import numpy as np
 

@@ -199,7 +199,7 @@ def test_c4_one_shard_of_the_billion_photon_job(gpu, c3):
     assert 0.03 < nhits / 1.25e8 < 0.15
 
 
-def _sharded_job(gpu, cfg, total, world_size):
+def _sharded_job(gpu, cfg, total, world_size, max_steps=100, use_weights=False):
     """The job bench.py --gpus N runs, with the N ranks taking their turns on ONE GPU: rank r propagates the photons of
     dist.shard_range(total, r, N) with their global ids, and what chroma_allreduce_hits does across ranks -- hit counts summed,
     earliest-time bit patterns reduced with MIN -- is done here on the host.  Returns (counts, earliest bits, seconds spent
@@ -214,7 +214,7 @@ def _sharded_job(gpu, cfg, total, world_size):
         gp = gpu.generate_bomb(end - begin, ENGINE_SEED, id_base=begin, wavelength_lo=400.0, wavelength_hi=0.0)
         gpu.get_context().synchronize()
         t0 = time.perf_counter()
-        gp.propagate(cfg.gg, _lib.Rng(ENGINE_SEED, begin), max_steps=100)
+        gp.propagate(cfg.gg, _lib.Rng(ENGINE_SEED, begin), max_steps=max_steps, use_weights=use_weights)
         c, e = gp.channel_hits(cfg.gg)
         c, e = c.get(), e.get()
         seconds += time.perf_counter() - t0
@@ -225,21 +225,38 @@ def _sharded_job(gpu, cfg, total, world_size):
     return counts, earliest, seconds
 
 
-def test_c4_the_whole_billion_photon_job_does_not_depend_on_the_sharding(gpu, c3):
+def test_c4_the_whole_billion_photon_job_on_one_gpu(gpu, c3):
     """BASELINE.json configs[3] (C4) in full on one GPU: 1e9 photons as the EIGHT shards of the 8-GPU job, one after the
-    other, reduced as the ranks would reduce them -- and the same billion photons as FIVE shards of 2e8.  A photon's random
-    stream is keyed by its global id and photons do not interact, so the reduced per-channel arrays must be the same bits
-    whatever the number of ranks: that is the whole correctness argument of the multi-GPU path, checked
-    here at the job's real size.  (What this cannot show is RCCL moving the 230 KB between GPUs: tests/test_gpu_comm.py,
-    tests/test_dist_cpu.py.)"""
+    other, reduced as the ranks would reduce them -- and the same billion photons as FIVE shards of 2e8.
+
+    Photons do not interact and a photon's random stream is keyed by its global id, so a photon's HISTORY does not depend on
+    the shard it is in.  Its float bits can, for the last photons of a batch, and that is the reference's own behaviour: once
+    fewer than 8192 photons of a batch are alive the reference finishes them in ONE launch and no longer re-normalises
+    dir / pol between steps (chroma/gpu/photon.py:227-230, chroma/cuda/propagate.cu:248,250); which photons that catches
+    depends on the batch.  Engine and oracle follow that policy (tests/test_oracle.py::
+    test_the_launch_policy_ties_the_last_photons_of_a_batch_to_their_batch), so a rank's result is the reference's for THAT
+    rank's batch, and two shardings of one job may differ in the last ulp of a few thousand photons per batch -- a handful of
+    which then cross a decision.  Checked here at the job's real size: the two shardings agree on all but a few hits in 1e8;
+    and where the policy does not look at the count (use_weights: every step in one launch, chroma/gpu/photon.py:227) the
+    reduced arrays are the same bits whatever the sharding.  (What this cannot show is RCCL moving the 230 KB between GPUs:
+    tests/test_gpu_comm.py, tests/test_dist_cpu.py.)"""
     total = 1_000_000_000
     c8, e8, s8 = _sharded_job(gpu, c3, total, 8)
     print('C4 on one GPU: 8 shards of 1.25e8 photons in %.2f s = %.3g photons/s' % (s8, total / s8))
-    assert 0.03 < int(c8.sum()) / total < 0.15
+    nhits = int(c8.sum())
+    assert 0.03 < nhits / total < 0.15
     assert (e8[c8 > 0] < 0x7f800000).all() and (e8[c8 == 0] == 0x7f800000).all()
     c5, e5, s5 = _sharded_job(gpu, c3, total, 5)
-    assert np.array_equal(c8, c5), 'per-channel hit counts depend on the sharding'
-    assert np.array_equal(e8, e5), 'earliest hit times depend on the sharding'
+    moved = int(np.abs(c8.astype(np.int64) - c5.astype(np.int64)).sum())
+    print('C4: 8 shards against 5 shards: %d of %d hits moved (%d channels), %d earliest times differ' % (
+        moved, nhits, int(np.count_nonzero(c8 != c5)), int(np.count_nonzero(e8 != e5))))
+    assert moved <= 1e-6 * nhits and abs(int(c5.sum()) - nhits) <= 1e-6 * nhits          # (measured: 8 of 6.8e7)
+    assert np.count_nonzero(e8 != e5) <= 1e-3 * len(e8)
+    # the policy does not depend on the count with weights: the same bits from any sharding
+    w4 = _sharded_job(gpu, c3, 20_000_000, 4, max_steps=10, use_weights=True)
+    w3 = _sharded_job(gpu, c3, 20_000_000, 3, max_steps=10, use_weights=True)
+    assert int(w4[0].sum()) > 0
+    assert np.array_equal(w4[0], w3[0]) and np.array_equal(w4[1], w3[1]), 'with weights the sharding must not matter'
 
 
 # ---- C2: demo.detector(), 10 055 PMTs, 59 M triangles (configs[1]) -----------------------------------------

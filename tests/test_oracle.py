@@ -81,6 +81,39 @@ def test_deterministic_and_thread_independent(oracle_mod, tiny_packed):
     assert not np.array_equal(d.flags, a.flags)
 
 
+def test_the_launch_policy_ties_the_last_photons_of_a_batch_to_their_batch(oracle_mod):
+    """Why the bits of a job sharded over GPUs can depend on the sharding, although photons do not interact and every photon
+    has the random stream of its global id: the reference runs one launch per step while at least 8192 photons of the BATCH are
+    alive and one launch for all remaining steps after that (chroma/gpu/photon.py:227-230), and every launch re-normalises
+    dir / pol on load (chroma/cuda/propagate.cu:248,250).  So the photons that outlive the switch are re-normalised or not
+    depending on how many OTHER photons their batch still holds.  The oracle restates that policy (the engine follows it:
+    tests/test_gpu_parity.py); here: a batch against its two halves.  Batches under 8192 photons never switch
+    (test_deterministic_and_thread_independent), and with weights every step runs in one launch whatever the count."""
+    pk = pack_geometry(make_stress_geometry())
+    n = 40000
+    ph = oracle_mod.generate_bomb(n, seed=21, wavelength_lo=350.0)
+    kw = dict(seed=77, max_steps=100, nthreads=4)
+    whole, cw, _ = oracle_mod.propagate(pk, ph, **kw)
+    lo, cl, _ = oracle_mod.propagate(pk, ph[:n // 2], photon_id_base=0, **kw)
+    hi, ch, _ = oracle_mod.propagate(pk, ph[n // 2:], photon_id_base=n // 2, **kw)
+    halves_pos = np.concatenate([lo.pos, hi.pos]).view(np.uint32)
+    halves_flags = np.concatenate([lo.flags, hi.flags])
+    same = (halves_pos == whole.pos.view(np.uint32)).all(axis=1) & (halves_flags == whole.flags)
+    # most photons end before either batch switches: the same bits; the stragglers differ in the last places, hardly ever in history
+    assert 0.5 < same.mean() < 1.0, same.mean()
+    assert (halves_flags == whole.flags).mean() > 0.995
+    m = halves_flags == whole.flags
+    assert np.allclose(np.concatenate([lo.pos, hi.pos])[m], whole.pos[m], rtol=1e-4, atol=1e-2)
+    # with weights the policy does not look at the count: a batch and its halves give the same bits
+    kw = dict(seed=77, max_steps=10, nthreads=4, use_weights=True)
+    whole, cw, _ = oracle_mod.propagate(pk, ph, **kw)
+    lo, cl, _ = oracle_mod.propagate(pk, ph[:n // 2], photon_id_base=0, **kw)
+    hi, ch, _ = oracle_mod.propagate(pk, ph[n // 2:], photon_id_base=n // 2, **kw)
+    for name in ('pos', 'dir', 'pol', 't', 'wavelengths', 'weights'):
+        assert np.array_equal(np.concatenate([getattr(lo, name), getattr(hi, name)]).view(np.uint32), getattr(whole, name).view(np.uint32)), name
+    assert np.array_equal(np.concatenate([lo.flags, hi.flags]), whole.flags) and np.array_equal(np.concatenate([cl, ch]), cw)
+
+
 def test_single_stepping_equals_one_call(oracle_mod):
     """propagate() may be called repeatedly (chroma/gpu/photon.py:199-200): ten calls of one
     step give the histories of one call of ten steps, thanks to the per-photon draw counter.
