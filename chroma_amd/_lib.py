@@ -157,6 +157,7 @@ SIGNATURES = {
     'chroma_render': (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
     'chroma_points_translate': (c_int32, [c_void_p, c_int32, c_void_p, POINTER(c_float)]),
     'chroma_points_rotate': (c_int32, [c_void_p, c_int32, c_void_p, c_float, POINTER(c_float)]),
+    'chroma_color_solids': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_uint32]),
     'chroma_points_rotate_around_point': (c_int32, [c_void_p, c_int32, c_void_p, c_float, POINTER(c_float), POINTER(c_float)]),
     'chroma_comm_unique_id': (c_int32, [c_void_p]),
     'chroma_comm_init': (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),

@@ -2118,6 +2118,20 @@ int chroma_render(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthreads, cons
     return CHROMA_OK;
 }
 
+int chroma_color_solids(chroma_ctx *ctx, chroma_geometry *geom, int32_t first_triangle, int32_t ntriangles, const uint8_t *d_solid_hit,
+                        const uint32_t *d_solid_colors, uint32_t nsolids)
+{
+    if (!ctx || !geom || !d_solid_hit || !d_solid_colors) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (!geom->d_colors || !geom->view.solid_id_map) return set_error(CHROMA_ERR_INVALID, "geometry was created without colors / solid_id_map");
+    if (first_triangle < 0 || ntriangles < 0 || (uint64_t)first_triangle + (uint64_t)ntriangles > (uint64_t)geom->ntriangles)
+        return set_error(CHROMA_ERR_INVALID, "triangles %d .. %lld of %llu", first_triangle, (long long)first_triangle + ntriangles, (unsigned long long)geom->ntriangles);
+    if (ntriangles == 0) return CHROMA_OK;
+    hipLaunchKernelGGL(k_color_solids, dim3((unsigned)((ntriangles + 255) / 256)), dim3(256), 0, ctx->stream, (int)first_triangle, (int)ntriangles,
+                       geom->view.solid_id_map, d_solid_hit, d_solid_colors, nsolids, (uint32_t *)geom->d_colors);
+    HIP_TRY(hipGetLastError());
+    return CHROMA_OK;
+}
+
 static int rays_transform(chroma_ctx *ctx, int32_t n, float *d_a, int mode, float phi, const float axis[3], const float point[3])
 {
     if (!ctx || !d_a) return set_error(CHROMA_ERR_INVALID, "bad argument");

@@ -247,6 +247,18 @@ k_render(GeoView g, const uint32_t *colors, int nthreads, const float *origin_in
     pixels[id] = av << 24 | red << 16 | green << 8 | blue;
 }
 
+// chroma/cuda/mesh.h:153-166 color_solids: the triangles of the solids marked in solid_hit take their solid's colour
+// (an id beyond the caller's arrays is left alone instead of read)
+__global__ void k_color_solids(int first_triangle, int nthreads, const uint32_t *solid_id_map, const uint8_t *solid_hit,
+                               const uint32_t *solid_colors, uint32_t nsolids, uint32_t *colors)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nthreads) return;
+    const int triangle_id = first_triangle + id;
+    const uint32_t solid_id = solid_id_map[triangle_id];
+    if (solid_id < nsolids && solid_hit[solid_id]) colors[triangle_id] = solid_colors[solid_id];
+}
+
 // chroma/cuda/transform.cu: translate / rotate / rotate_around_point of a point array
 __global__ void k_rays_transform(int n, float *a, int mode, float phi, float ax, float ay, float az, float px, float py, float pz)
 {

@@ -130,11 +130,18 @@ def _distance_to_mesh(nthreads, origin, direction, geometry, distance, block=Non
                                                 distance.ptr, None))
 
 
+def _color_solids(first_triangle, nthreads, solid_id_map, solid_hit, solid_colors, geometry, block=None, grid=None):
+    # (solid_id_map is the geometry's own array; the kernel reads it from the handle)
+    ctx = solid_colors.ctx
+    _lib.check(ctx._lib.chroma_color_solids(ctx.handle, geometry, _scalar(first_triangle), _scalar(nthreads), solid_hit.ptr,
+                                            solid_colors.ptr, min(len(solid_hit), len(solid_colors))))
+
+
 _MODULES = {
     'propagate.cu': {'photon_duplicate': _photon_duplicate, 'count_photons': _count_photons, 'copy_photons': _copy_photons,
                      'copy_photon_queue': _copy_photon_queue, 'count_photon_hits': _count_photon_hits,
                      'copy_photon_hits': _copy_photon_hits, 'propagate': _propagate},
-    'mesh.h': {'distance_to_mesh': _distance_to_mesh},
+    'mesh.h': {'distance_to_mesh': _distance_to_mesh, 'color_solids': _color_solids},
 }
 
 

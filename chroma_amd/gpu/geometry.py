@@ -326,6 +326,20 @@ class GPUGeometry(object):
         print(self.device_usage_str())
         print()
 
+    def color_solids(self, solid_hit, colors, nblocks_per_thread=64, max_blocks=1024):
+        """The triangles of every solid marked in ``solid_hit`` (one bool per solid) take that solid's entry of ``colors``
+        (chroma/gpu/geometry.py:283-298, kernel color_solids of chroma/cuda/mesh.h:153-166); ``reset_colors`` undoes it.
+        The launch-shape arguments are accepted and ignored."""
+        solid_hit = np.ascontiguousarray(np.asarray(solid_hit, dtype=bool)).view(np.uint8)
+        colors = np.ascontiguousarray(colors, dtype=np.uint32)
+        if len(solid_hit) != len(colors):
+            raise ValueError('solid_hit and colors must have one entry per solid (%d, %d)' % (len(solid_hit), len(colors)))
+        hit_gpu = GPUArray(len(solid_hit), np.uint8, self.ctx).set(solid_hit)
+        colors_gpu = GPUArray(len(colors), np.uint32, self.ctx).set(colors)
+        _lib.check(self.ctx._lib.chroma_color_solids(self.ctx.handle, self.handle, 0, self.triangles.size, hit_gpu.ptr, colors_gpu.ptr,
+                                                     len(colors)))
+        self.ctx.synchronize()          # (the two small arrays go out of scope here)
+
     def reset_colors(self):
         self.colors.set(self.geometry.colors.astype(np.uint32))
 

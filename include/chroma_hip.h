@@ -389,6 +389,12 @@ int chroma_photons_sort_direction(chroma_ctx *ctx, const chroma_photon_arrays *p
  * front to back over bg_color into d_pixels [n] (0xAARRGGBB).  Directions are used as given (not normalised). */
 int chroma_render(chroma_ctx *ctx, chroma_geometry *geom, int32_t nthreads, const float *d_origin, const float *d_direction,
                   uint32_t alpha_depth, uint32_t *d_pixels, float *d_dx, uint32_t *d_dxlen, float *d_color, uint32_t bg_color);
+/* `color_solids` (chroma/cuda/mesh.h:153-166; host: GPUGeometry.color_solids, chroma/gpu/geometry.py:283-298): triangle t of
+ * [first_triangle, first_triangle + ntriangles) takes d_solid_colors[solid_id_map[t]] where d_solid_hit[solid_id_map[t]] is set
+ * (one byte per solid, as numpy bool); both arrays hold `nsolids` entries, a triangle of a solid beyond them keeps its colour.
+ * Writes the geometry's `colors` array, the one chroma_render reads. */
+int chroma_color_solids(chroma_ctx *ctx, chroma_geometry *geom, int32_t first_triangle, int32_t ntriangles, const uint8_t *d_solid_hit,
+                        const uint32_t *d_solid_colors, uint32_t nsolids);
 /* `translate`, `rotate`, `rotate_around_point` (chroma/cuda/transform.cu:9-53) on a float3 array */
 int chroma_points_translate(chroma_ctx *ctx, int32_t n, float *d_a, const float v[3]);
 int chroma_points_rotate(chroma_ctx *ctx, int32_t n, float *d_a, float phi, const float axis[3]);

@@ -101,3 +101,50 @@ def test_render_matches_oracle_and_compiled_reference(oracle_mod, tiny_geometry,
             rays.render(gg, np.zeros(len(o), np.uint32))
     finally:
         ctx.pop()
+
+
+def test_color_solids_recolours_the_marked_solids_and_render_sees_it(tiny_geometry):
+    """GPUGeometry.color_solids (chroma/gpu/geometry.py:283-298, kernel color_solids of chroma/cuda/mesh.h:153-166): the
+    triangles of the marked solids take their solid's colour, every other triangle keeps its own -- against NumPy -- through
+    the method and through the kernel table (get_cu_module('mesh.h').color_solids, a slice of the triangles); reset_colors
+    undoes it; the render kernel reads the recoloured array."""
+    from chroma_amd import gpu
+    from chroma_amd.gpu.tools import GPUArray
+    ctx = gpu.create_cuda_context(0)
+    try:
+        gg = gpu.GPUGeometry(tiny_geometry)
+        solid_id = np.asarray(tiny_geometry.solid_id)
+        nsolids = int(solid_id.max()) + 1
+        before = gg.colors.get()
+        rng = np.random.default_rng(5)
+        hit = rng.random(nsolids) < 0.3
+        new = rng.integers(0, 1 << 32, nsolids, dtype=np.uint64).astype(np.uint32)
+        gg.color_solids(hit, new)
+        want = np.where(hit[solid_id], new[solid_id], before)
+        assert hit.any() and not hit.all() and not np.array_equal(want, before)
+        assert np.array_equal(gg.colors.get(), want)
+        gg.reset_colors()
+        assert np.array_equal(gg.colors.get(), before)
+        # the reference's kernel by name, on a slice of the triangles
+        first, count = 1000, len(solid_id) // 2
+        fn = gpu.get_cu_module('mesh.h').get_function('color_solids')
+        hit_gpu = GPUArray(nsolids, np.uint8, ctx).set(hit.view(np.uint8))
+        new_gpu = GPUArray(nsolids, np.uint32, ctx).set(new)
+        fn(np.int32(first), np.int32(count), gg.solid_id_map, hit_gpu, new_gpu, gg.gpudata, block=(64, 1, 1), grid=(count // 64 + 1, 1))
+        want2 = before.copy()
+        want2[first:first + count] = want[first:first + count]
+        assert np.array_equal(gg.colors.get(), want2)
+        with pytest.raises(Exception):
+            fn(np.int32(0), np.int32(len(solid_id) + 1), gg.solid_id_map, hit_gpu, new_gpu, gg.gpudata)
+        # a ray that meets a recoloured solid first shows its colour
+        gg.reset_colors()
+        gg.color_solids(np.ones(nsolids, bool), np.full(nsolids, 0x00FF0000, np.uint32))       # opaque (alpha byte 0) pure red
+        d = rng.normal(size=(256, 3)).astype(np.float32)
+        rays = gpu.GPURays(np.zeros((256, 3), np.float32), d / np.linalg.norm(d, axis=1)[:, None])
+        pixels = GPUArray(256, np.uint32, ctx)
+        rays.render(gg, pixels, alpha_depth=2)
+        px = pixels.get()
+        seen = px != 0                  # (rays that meet nothing keep the background)
+        assert seen.sum() > 100 and ((px[seen] & 0x00FFFF) == 0).all() and ((px[seen] >> 16) & 0xFF).max() > 100, hex(int(px[seen][0]))
+    finally:
+        ctx.pop()
