@@ -16,6 +16,7 @@ stream keyed by the GLOBAL photon id) and the per-GPU work is fixed (weak scalin
 shard is 1.25e8 photons (BASELINE.json configs[3]: 1e9 photons over 8 GPUs).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 from ctypes import c_uint32 as ctypes_uint32
 import hashlib
 import json
@@ -393,8 +394,15 @@ def main():
 
     for i in range(args.warmup):
         t_step = time.perf_counter()
-        run_step(batch_for(i), False, {})
+        # (kernels timed as in the timed steps: the library creates its HIP events at the first timed call -- 6 per step of
+        #  max_steps, ~2 ms -- and that set-up belongs to the warm-up, not to a step)
+        run_step(batch_for(i), True, {})
         log('  warmup %d: %.1f ms wall' % (i, 1e3 * (time.perf_counter() - t_step)))
+    # (the garbage of the set-up -- the packed geometry's 6-17 GB of mapped host arrays above all -- is collected HERE: a
+    #  collection that starts inside a step costs it ~40 ms of munmap, measured as a one-step outlier whenever the interpreter
+    #  happened to schedule one there; nothing the timed loop allocates needs the cycle collector)
+    gc.collect()
+    gc.disable()
     sync_all()
     stats = {}
     step_walls = []
@@ -407,6 +415,7 @@ def main():
         log('  step %d: %.1f ms wall, %.1f ms in propagate kernels' % (i - args.warmup, 1e3 * step_walls[-1], stats['kernel_ms'] - k0))
     sync_all()
     elapsed = time.perf_counter() - t_start
+    gc.enable()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -467,13 +476,18 @@ def main():
         headline, kernels timed by HIP events on the library's stream); `prepare(i)` returns batch i with its input ready
         BEFORE the clock starts.  Returns the walls and the summed statistics."""
         walls, leg_stats = [], {}
-        for i in range(nleg):
-            b = prepare(i)
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            run_step(b, True, leg_stats)
-            ctx.synchronize()
-            walls.append(time.perf_counter() - t0)
+        gc.collect()
+        gc.disable()                  # (as in the headline loop: no cycle collection inside a batch)
+        try:
+            for i in range(nleg):
+                b = prepare(i)
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                run_step(b, True, leg_stats)
+                ctx.synchronize()
+                walls.append(time.perf_counter() - t0)
+        finally:
+            gc.enable()
         return walls, leg_stats
 
     def leg_roofline(leg, leg_stats, nodes_per_step, tris_per_step, steps_per_photon, nleg):
