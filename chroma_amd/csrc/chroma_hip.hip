@@ -2152,7 +2152,7 @@ int chroma_points_rotate_around_point(chroma_ctx *ctx, int32_t n, float *d_a, fl
 int chroma_probe(chroma_ctx *ctx, int32_t fn, uint64_t n, const float *d_x, const float *d_tab_x, const float *d_tab_f,
                  uint32_t ntab, float start, float step, float *d_out)
 {
-    if (!ctx || !d_x || !d_out || fn < 0 || fn > 3) return set_error(CHROMA_ERR_INVALID, "bad argument");
+    if (!ctx || !d_x || !d_out || fn < 0 || fn > 4) return set_error(CHROMA_ERR_INVALID, "bad argument");
     if ((fn == 0 && (!d_tab_f || ntab < 2)) || (fn == 1 && (!d_tab_x || ntab < 2)) || (fn == 2 && (!d_tab_x || !d_tab_f || ntab < 2)))
         return set_error(CHROMA_ERR_INVALID, "probe %d: table missing", fn);
     if (n == 0) return CHROMA_OK;

@@ -312,10 +312,23 @@ __global__ void k_probe(int fn, uint64_t n, const float *x, const float *tab_x, 
         out[i] = interp_idx(x[i], (int)ntab, tab_x);
     } else if (fn == 2) {
         out[i] = interp_table(x[i], (int)ntab, tab_x, tab_f);
-    } else {
+    } else if (fn == 3) {
         const float *p = x + 7 * i;
         v3 r = rotate(mk3(p[0], p[1], p[2]), p[3], mk3(p[4], p[5], p[6]));
         float *o = out + 5 * i;
         o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = cm_cosf(p[3]); o[4] = cm_sinf(p[3]);
+    } else {
+        // the float3 algebra every device function of the path is written in (device_common.h; chroma/cuda/linalg.h)
+        const float *p = x + 7 * i;
+        const v3 a = mk3(p[0], p[1], p[2]), b = mk3(p[3], p[4], p[5]);
+        const float c = p[6];
+        float *o = out + 32 * i;
+        const v3 r[8] = {-a, a + b, a - b, a * c, c * a, a / c, c / a, cross(a, b)};
+        for (int k = 0; k < 8; k++) { o[3 * k] = r[k].x; o[3 * k + 1] = r[k].y; o[3 * k + 2] = r[k].z; }
+        o[24] = dot(a, b);
+        o[25] = norm(a);
+        const v3 u = normalize(a), q = a / b;
+        o[26] = u.x; o[27] = u.y; o[28] = u.z;
+        o[29] = q.x; o[30] = q.y; o[31] = q.z;
     }
 }

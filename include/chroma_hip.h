@@ -423,7 +423,9 @@ int chroma_allreduce_daq(chroma_ctx *ctx, uint32_t *d_earliest_time_int, uint32_
  *   fn 0  interp_property (chroma/cuda/geometry.h:64-75)   d_x[n], d_tab_f[ntab], grid (start, step)
  *   fn 1  interp_idx (chroma/cuda/interpolate.h:5-29)      d_x[n], d_tab_x[ntab]
  *   fn 2  interp (chroma/cuda/interpolate.h:32-57)         d_x[n], d_tab_x[ntab], d_tab_f[ntab]
- *   fn 3  rotate (chroma/cuda/rotate.h:22-28)              d_x[7 n] = a.xyz, phi, axis.xyz -> d_out[5 n] = r.xyz, cos phi, sin phi */
+ *   fn 3  rotate (chroma/cuda/rotate.h:22-28)              d_x[7 n] = a.xyz, phi, axis.xyz -> d_out[5 n] = r.xyz, cos phi, sin phi
+ *   fn 4  the float3 algebra (chroma/cuda/linalg.h)        d_x[7 n] = a.xyz, b.xyz, c -> d_out[32 n] = -a, a+b, a-b, a*c, c*a, a/c, c/a,
+ *                                                          cross(a,b), dot(a,b), norm(a), normalize(a), a/b */
 int chroma_probe(chroma_ctx *ctx, int32_t fn, uint64_t n, const float *d_x, const float *d_tab_x, const float *d_tab_f,
                  uint32_t ntab, float start, float step, float *d_out);
 
