@@ -112,7 +112,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--warmup', type=int, default=2)        # (the first ~0.25 s of sustained load run 1.6 % slower: two batches at C3)
     ap.add_argument('--config', default=os.environ.get('CHROMA_BENCH_CONFIG', 'c3'), choices=sorted(CONFIGS))
     ap.add_argument('--photons', type=int, default=0, help='photons per GPU per step (default: the config\'s)')
     ap.add_argument('--max-steps', type=int, default=100)
@@ -392,6 +392,7 @@ def main():
     def batch_for(i):
         return buffers[i] if resident else buffers[i % nbuffers].fill(i)
 
+    sync_all()          # (the first torch.cuda.synchronize() of the process initialises torch's side of the runtime: before the warm-up, not after it)
     for i in range(args.warmup):
         t_step = time.perf_counter()
         # (kernels timed as in the timed steps: the library creates its HIP events at the first timed call -- 6 per step of
