@@ -7,6 +7,7 @@ This module takes the place of chroma/gpu/tools.py (PyCUDA): ``create_cuda_conte
 """
 import ctypes
 import os
+import threading
 import weakref
 
 import numpy as np
@@ -42,6 +43,7 @@ def to_uint3(arr):
 
 # ---- context ----------------------------------------------------------------------------------
 _current = None
+_bound = threading.local()      # a context bound to THIS thread (Context.bound()) goes before the process-wide current one
 
 
 class Context(object):
@@ -69,6 +71,12 @@ class Context(object):
         self.synchronize()
         if _current is self:
             _current = None
+
+    def bound(self):
+        """``with ctx.bound():`` -- this context is what get_context() returns IN THIS THREAD for the duration of the block,
+        whatever the process-wide current context is: several host threads, each driving its own context on the one GPU
+        (Simulation(lanes=K)), without touching each other's idea of "the current context"."""
+        return _Bound(self)
 
     def detach(self):
         self.pop()
@@ -150,6 +158,20 @@ class Context(object):
         return stats.as_dict()
 
 
+class _Bound(object):
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.previous = getattr(_bound, 'ctx', None)
+        _bound.ctx = self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _bound.ctx = self.previous
+        return False
+
+
 def create_cuda_context(device_id=None, library=None):
     """Initialise the device and return the (now current) context.  ``library``: path of another build
     of libchroma_hip.so to run this context's calls through (tests, A/B experiments)."""
@@ -161,6 +183,9 @@ def create_cuda_context(device_id=None, library=None):
 def get_context():
     """The current context; created on device 0 on first use."""
     global _current
+    ctx = getattr(_bound, 'ctx', None)
+    if ctx is not None:
+        return ctx
     if _current is None:
         create_cuda_context(None)
     return _current

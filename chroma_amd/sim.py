@@ -21,7 +21,7 @@ def pick_seed():
 
 class Simulation(object):
     def __init__(self, detector, seed=None, cuda_device=None, particle_tracking=False, photon_tracking=False,
-                 geant4_processes=0, nthreads_per_block=64, max_blocks=1024, exact=False, prefetch=True):
+                 geant4_processes=0, nthreads_per_block=64, max_blocks=1024, exact=False, prefetch=True, lanes=1):
         # ``exact``: propagate with the reference's own traversal loop for every ray (GPUPhotons.propagate(exact=True)):
         # the reference's hit triangle on every ray, several times slower than the default walk
         self.exact = bool(exact)
@@ -30,6 +30,18 @@ class Simulation(object):
         # library's pool, so after the first two batches nothing is allocated.  The user's iterable is read one batch
         # ahead of the events that are yielded.
         self.prefetch = bool(prefetch)
+        # ``lanes`` > 1: simulate() keeps that many batches in flight at once, each on a context of its own (its own streams,
+        # queues and working sets; the geometry is uploaded once per lane) driven by a host thread of its own.  On the DEVICE
+        # a batch of 1e4-1e6 photons is launch- and latency-bound -- a step under ~1e5 rays lasts as long as its longest ray,
+        # the last 8192 photons as long as the longest photon -- and several in flight fill the chip: 2.8 x the photons per
+        # second at 1e4 photons per batch, 2 x at 1e6, 1.3 x at 1e7, nothing at 1e8 (device photons, tools/concurrency_probe.py,
+        # profiles/r04/concurrency_probe.txt).  END TO END, with host photons in and Python event objects out, the host side
+        # of a batch (staging, per-channel hit dictionaries) is most of its time and the lanes share the interpreter: from
+        # 2.3 x (1e6-photon events on a 501-PMT detector, keep_hits=True) to 0.6 x (1e5-photon events on demo.tiny()),
+        # profiles/r04/sim_lanes_probe.txt -- so the default is 1.  Results are those of lanes=1 bit for bit (a photon's random
+        # stream is keyed by its global id, handed out in batch order) and are yielded in order.  Not used with photon
+        # tracking, keep_photons_beg or run_daq (those take the one-batch-at-a-time loop).
+        self.nlanes = max(1, int(lanes))
         self.detector = detector
         self.nthreads_per_block = nthreads_per_block
         self.max_blocks = max_blocks
@@ -43,11 +55,20 @@ class Simulation(object):
             from chroma_amd.loader import load_bvh
             detector.flatten()
             detector.bvh = load_bvh(detector)
+        make = gpu.GPUDetector if hasattr(detector, 'num_channels') else gpu.GPUGeometry
+        packed = None
+        if self.nlanes > 1:
+            from chroma_amd.gpu.geometry import pack_geometry
+            packed = pack_geometry(detector)          # packed once, uploaded once per lane
+        self.gpu_geometry = make(detector, packed=packed)
         if hasattr(detector, 'num_channels'):
-            self.gpu_geometry = gpu.GPUDetector(detector)
             self.gpu_daq = gpu.GPUDaq(self.gpu_geometry)
-        else:
-            self.gpu_geometry = gpu.GPUGeometry(detector)
+        self._lanes = [(self.context, self.gpu_geometry)]
+        for _ in range(1, self.nlanes):
+            ctx = gpu.tools.Context(self.context.device_id)
+            with ctx.bound():
+                self._lanes.append((ctx, make(detector, packed=packed)))
+        packed = None
         self.rng_states = gpu.get_rng_states(self.nthreads_per_block * self.max_blocks, seed=self.seed)
         self.pdf_config = None
 
@@ -65,10 +86,12 @@ class Simulation(object):
         return gpu.GPUPhotons(batch_photons, copy_triangles=False, copy_weights=False, upload=upload), bounds
 
     def _simulate_batch(self, batch_events, keep_photons_beg=False, keep_photons_end=False, keep_hits=True,
-                        keep_flat_hits=True, run_daq=False, max_steps=100, verbose=False, uploaded=None):
+                        keep_flat_hits=True, run_daq=False, max_steps=100, verbose=False, uploaded=None, gpu_geometry=None):
         """Propagate the photons of all ``batch_events`` in one go and split the results
-        back per event (by evidx).  Yields the events.  ``uploaded``: what _upload_batch returned for them."""
+        back per event (by evidx).  Yields the events.  ``uploaded``: what _upload_batch returned for them;
+        ``gpu_geometry``: the geometry of the lane this batch runs on (default: the simulation's own)."""
         t_start = timer()
+        geometry = gpu_geometry if gpu_geometry is not None else self.gpu_geometry
         if uploaded is None:
             uploaded = self._upload_batch(batch_events, upload=False)
         gpu_photons, bounds = uploaded
@@ -78,9 +101,9 @@ class Simulation(object):
         batch_hits = tracking = None
         if want_hits and not self.photon_tracking:
             # propagate + get_flat_hits as one library call (chroma_propagate_hits): the same set of hits
-            batch_hits = gpu_photons.propagate_hits(self.gpu_geometry, self.rng_states, max_steps=max_steps, exact=self.exact)
+            batch_hits = gpu_photons.propagate_hits(geometry, self.rng_states, max_steps=max_steps, exact=self.exact)
         else:
-            tracking = gpu_photons.propagate(self.gpu_geometry, self.rng_states,
+            tracking = gpu_photons.propagate(geometry, self.rng_states,
                                              nthreads_per_block=self.nthreads_per_block, max_blocks=self.max_blocks,
                                              max_steps=max_steps, track=self.photon_tracking, exact=self.exact)
         t_prop = timer()
@@ -90,7 +113,7 @@ class Simulation(object):
 
         batch_end = gpu_photons.get() if keep_photons_end else None
         if want_hits and batch_hits is None:
-            batch_hits = gpu_photons.get_flat_hits(self.gpu_geometry)
+            batch_hits = gpu_photons.get_flat_hits(geometry)
 
         # the hits of each event: one stable sort by event index and slices of it (views) instead of one boolean mask
         # over all hits per event (chroma/sim.py:118-121 does the latter: quadratic in the number of events)
@@ -179,6 +202,9 @@ class Simulation(object):
         # (read-ahead contract: with prefetch the iterable is pulled one batch ahead of the events being yielded, and `evidx` is
         #  written into the photons of that next batch early; a generator that reuses its buffers, or a caller who wants
         #  `photons_beg` back untouched, gets the reference's lazy loop instead)
+        if self.nlanes > 1 and not (self.photon_tracking or keep_photons_beg or run_daq):
+            yield from self._simulate_lanes(batches(), kwargs)
+            return
         if not self.prefetch or self.photon_tracking or keep_photons_beg:
             for batch in batches():
                 yield from self._simulate_batch(batch, **kwargs)
@@ -198,8 +224,39 @@ class Simulation(object):
                 uploaded = None
                 cur = nxt
 
+    def _simulate_lanes(self, batches, kwargs):
+        """``lanes`` batches in flight at once, each on its own context from its own host thread (the library calls
+        release the GIL); events come back in the order of the iterable.  The photon-id block of a batch (its random
+        streams) is reserved HERE, in batch order, so the results are those of the one-batch-at-a-time loop."""
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
+        def work(lane, batch, rng_base):
+            ctx, geometry = self._lanes[lane]
+            with ctx.bound():
+                uploaded = self._upload_batch(batch, upload=False)
+                uploaded[0]._rng_base, uploaded[0]._rng_owner = rng_base, self.rng_states
+                return list(self._simulate_batch(batch, uploaded=uploaded, gpu_geometry=geometry, **kwargs))
+
+        with ThreadPoolExecutor(max_workers=self.nlanes) as pool:
+            free, pending = deque(range(self.nlanes)), deque()
+            for batch in batches:
+                if not free:
+                    lane, fut = pending.popleft()
+                    events = fut.result()
+                    free.append(lane)
+                    yield from events
+                lane = free.popleft()
+                base = self.rng_states.reserve(sum(len(ev.photons_beg) for ev in batch))
+                pending.append((lane, pool.submit(work, lane, batch, base)))
+            while pending:
+                lane, fut = pending.popleft()
+                yield from fut.result()
+
     def __del__(self):
         try:
+            for ctx, geometry in self._lanes[1:]:
+                ctx.synchronize()
             self.context.pop()
         except Exception:
             pass

@@ -82,3 +82,40 @@ def test_simulation_with_prefetch_equals_simulation_without(gpu, tiny_geometry, 
         assert len(hitsa) == len(hitsb) > 0
         oa, ob = np.lexsort((hitsa.t, hitsa.channel)), np.lexsort((hitsb.t, hitsb.channel))
         assert np.array_equal(hitsa.channel[oa], hitsb.channel[ob]) and np.array_equal(hitsa.t[oa].view(np.uint32), hitsb.t[ob].view(np.uint32))
+
+
+def test_simulation_with_lanes_equals_one_batch_at_a_time(gpu, tiny_geometry, oracle_mod):
+    """Simulation(lanes=3): three batches in flight at once, each on its own context from its own host thread.  Twelve
+    batches of events of uneven sizes: the events come back in order with the photons and hits of the one-batch-at-a-time
+    loop, bit for bit (a batch's photon-id block is reserved in batch order whatever lane runs it); the contexts of the
+    lanes leave the process-wide current context alone; and small batches go through faster."""
+    import time
+    from chroma_amd.sim import Simulation
+
+    sizes = [7000, 15000, 3000, 12000, 9000, 20000] * 6
+
+    def events():
+        for k, n in enumerate(sizes):
+            yield oracle_mod.generate_bomb(n, seed=300 + k)
+
+    results, seconds = {}, {}
+    for lanes in (1, 3):
+        sim = Simulation(tiny_geometry, seed=78, lanes=lanes)
+        current = gpu.get_context()
+        assert current is sim.context and len(sim._lanes) == lanes
+        list(sim.simulate(events(), photons_per_batch=30000, max_steps=100))        # (warm the lanes' pools and working sets)
+        sim.rng_states.next_photon_id = 0
+        t0 = time.perf_counter()
+        out = [(ev.id, ev.photons_end, ev.flat_hits) for ev in sim.simulate(events(), keep_photons_end=True, photons_per_batch=30000, max_steps=100)]
+        seconds[lanes] = time.perf_counter() - t0
+        results[lanes] = out
+        assert gpu.get_context() is current
+        del sim
+    assert [r[0] for r in results[1]] == list(range(len(sizes))) == [r[0] for r in results[3]]
+    for (ida, enda, hitsa), (idb, endb, hitsb) in zip(results[1], results[3]):
+        assert len(enda) == sizes[ida]
+        assert_bit_exact(enda, endb, 'event %d with one lane and with three' % ida)
+        assert len(hitsa) == len(hitsb)
+        oa, ob = np.lexsort((hitsa.t, hitsa.channel)), np.lexsort((hitsb.t, hitsb.channel))
+        assert np.array_equal(hitsa.channel[oa], hitsb.channel[ob]) and np.array_equal(hitsa.t[oa].view(np.uint32), hitsb.t[ob].view(np.uint32))
+    print('Simulation over %d photons in batches of 3e4: %.1f ms with one lane, %.1f ms with three' % (sum(sizes), 1e3 * seconds[1], 1e3 * seconds[3]))
