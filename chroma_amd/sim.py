@@ -36,9 +36,8 @@ class Simulation(object):
         # the last 8192 photons as long as the longest photon -- and several in flight fill the chip: 2.8 x the photons per
         # second at 1e4 photons per batch, 2 x at 1e6, 1.3 x at 1e7, nothing at 1e8 (device photons, tools/concurrency_probe.py,
         # profiles/r04/concurrency_probe.txt).  END TO END, with host photons in and Python event objects out, the host side
-        # of a batch (staging, per-channel hit dictionaries) is most of its time and the lanes share the interpreter: from
-        # 2.3 x (1e6-photon events on a 501-PMT detector, keep_hits=True) to 0.6 x (1e5-photon events on demo.tiny()),
-        # profiles/r04/sim_lanes_probe.txt -- so the default is 1.  Results are those of lanes=1 bit for bit (a photon's random
+        # of a batch (staging, event objects, hit dictionaries) is most of its time and the lanes share the interpreter: 1.0-1.8 x
+        # with four lanes, 0.9-1.3 x with two (profiles/r04/sim_lanes_probe.txt) -- so the default is 1.  Results are those of lanes=1 bit for bit (a photon's random
         # stream is keyed by its global id, handed out in batch order) and are yielded in order.  Not used with photon
         # tracking, keep_photons_beg or run_daq (those take the one-batch-at-a-time loop).
         self.nlanes = max(1, int(lanes))
@@ -147,7 +146,13 @@ class Simulation(object):
             if batch_hits is not None:
                 ev_hits = per_event_hits[i]
                 if keep_hits:
-                    ev.hits = {int(ch): ev_hits[ev_hits.channel == ch] for ch in np.unique(ev_hits.channel)}
+                    # per-channel hits: one stable sort by channel and slices of it, instead of one boolean mask over all
+                    # hits per channel (chroma/sim.py:122-123 does the latter: hits x channels -- 2e11 element tests for
+                    # one 1e8-photon batch on a 29k-channel detector); the same photons in the same order per channel
+                    by_channel = ev_hits[np.argsort(ev_hits.channel, kind='stable')]
+                    channels, first = np.unique(by_channel.channel, return_index=True)
+                    last = np.append(first[1:], len(by_channel))
+                    ev.hits = {int(ch): by_channel[a:b] for ch, a, b in zip(channels, first, last)}
                 if keep_flat_hits:
                     ev.flat_hits = ev_hits
             if hasattr(self, 'gpu_daq') and run_daq:

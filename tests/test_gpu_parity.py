@@ -301,6 +301,13 @@ def test_simulation_batching_and_per_event_split(gpu, tiny_geometry):
         assert len(ev.flat_hits) <= det.sum()
         assert sum(len(v) for v in ev.hits.values()) == len(ev.flat_hits)
         assert (ev.flat_hits.flags & event.SURFACE_DETECT != 0).all()
+        # ev.hits comes from ONE sort of the event's hits by channel: per channel the photons the reference's mask
+        # (chroma/sim.py:122-123: flat_hits[flat_hits.channel == channel]) selects, in the same order
+        assert sorted(ev.hits) == sorted(int(c) for c in np.unique(ev.flat_hits.channel))
+        for ch, got in ev.hits.items():
+            want = ev.flat_hits[ev.flat_hits.channel == ch]
+            assert len(got) == len(want) > 0 and (got.channel == ch).all()
+            assert np.array_equal(got.t.view(np.uint32), want.t.view(np.uint32)) and np.array_equal(got.pos.view(np.uint32), want.pos.view(np.uint32))
 
 
 def test_simulation_exact_switch_and_per_event_hits(gpu, oracle_mod, tiny_geometry):
