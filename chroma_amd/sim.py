@@ -19,6 +19,15 @@ def pick_seed():
     return int(time.time()) ^ (os.getpid() << 16) & 2 ** 32 - 1
 
 
+def _stable_order(keys):
+    """argsort(keys, kind='stable'); small non-negative integer keys (channels, event indices) go through NumPy's radix
+    sort for 16-bit integers instead of a merge sort."""
+    k = np.asarray(keys)
+    if len(k) and k.dtype.kind in 'iu' and int(k.min()) >= 0 and int(k.max()) < 65536:
+        k = k.astype(np.uint16)
+    return np.argsort(k, kind='stable')
+
+
 class Simulation(object):
     def __init__(self, detector, seed=None, cuda_device=None, particle_tracking=False, photon_tracking=False,
                  geant4_processes=0, nthreads_per_block=64, max_blocks=1024, exact=False, prefetch=True, lanes=1):
@@ -114,15 +123,22 @@ class Simulation(object):
         if want_hits and batch_hits is None:
             batch_hits = gpu_photons.get_flat_hits(geometry)
 
-        # the hits of each event: one stable sort by event index and slices of it (views) instead of one boolean mask
-        # over all hits per event (chroma/sim.py:118-121 does the latter: quadratic in the number of events)
+        # The hits of each event, and within an event of each channel: ONE ordering of the batch's hits -- by channel, then
+        # (stably) by event -- one gather, and slices of it (views), instead of one boolean mask over all hits per event and
+        # then per channel (chroma/sim.py:118-123: hits x events + hits x channels element tests -- 2e11 for one 1e8-photon
+        # batch on a 29k-channel detector).  Keys below 65 536 are sorted as uint16, which NumPy sorts by radix.
         per_event_hits = None
         if batch_hits is not None:
+            order = None
+            if keep_hits and len(batch_hits):
+                order = _stable_order(batch_hits.channel)
+            if len(batch_events) > 1 and len(batch_hits):
+                by_event = _stable_order(batch_hits.evidx if order is None else batch_hits.evidx[order])
+                order = by_event if order is None else order[by_event]
+            sorted_hits = batch_hits if order is None else batch_hits[order]
             if len(batch_events) == 1:
-                per_event_hits = [batch_hits]
+                per_event_hits = [sorted_hits]
             else:
-                order = np.argsort(batch_hits.evidx, kind='stable')
-                sorted_hits = batch_hits[order]
                 cuts = np.searchsorted(sorted_hits.evidx, np.arange(len(batch_events) + 1))
                 per_event_hits = [sorted_hits[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
         for i, (ev, lo, hi) in enumerate(zip(batch_events, bounds[:-1], bounds[1:])):
@@ -146,13 +162,10 @@ class Simulation(object):
             if batch_hits is not None:
                 ev_hits = per_event_hits[i]
                 if keep_hits:
-                    # per-channel hits: one stable sort by channel and slices of it, instead of one boolean mask over all
-                    # hits per channel (chroma/sim.py:122-123 does the latter: hits x channels -- 2e11 element tests for
-                    # one 1e8-photon batch on a 29k-channel detector); the same photons in the same order per channel
-                    by_channel = ev_hits[np.argsort(ev_hits.channel, kind='stable')]
-                    channels, first = np.unique(by_channel.channel, return_index=True)
-                    last = np.append(first[1:], len(by_channel))
-                    ev.hits = {int(ch): by_channel[a:b] for ch, a, b in zip(channels, first, last)}
+                    # (the event's hits are in channel order already: a channel's hits are one slice)
+                    channels, first = np.unique(ev_hits.channel, return_index=True)
+                    last = np.append(first[1:], len(ev_hits))
+                    ev.hits = {int(ch): ev_hits[a:b] for ch, a, b in zip(channels, first, last)}
                 if keep_flat_hits:
                     ev.flat_hits = ev_hits
             if hasattr(self, 'gpu_daq') and run_daq:
