@@ -267,7 +267,13 @@ class GPUPhotons(object):
     def get_hits(self, *args, **kwargs):
         """dict channel -> Photons detected on that channel."""
         flat = self.get_flat_hits(*args, **kwargs)
-        return {int(ch): flat[flat.channel == ch] for ch in np.unique(flat.channel)}
+        # one stable sort by channel and slices of it (chroma/gpu/photon.py:96-105 masks all hits once per channel): the same
+        # photons per channel in the same order
+        keys = flat.channel.astype(np.uint16) if len(flat) and int(flat.channel.max()) < 65536 else flat.channel
+        by_channel = flat[np.argsort(keys, kind='stable')]
+        channels, first = np.unique(by_channel.channel, return_index=True)
+        last = np.append(first[1:], len(by_channel))
+        return {int(ch): by_channel[a:b] for ch, a, b in zip(channels, first, last)}
 
     def get_flat_hits(self, gpu_detector, target_flag=(0x1 << 2), nthreads_per_block=64, max_blocks=1024,
                       start_photon=None, nphotons=None, no_map=False):
