@@ -109,6 +109,13 @@ class Photons(object):
         return len(self.pos)
 
     def __getitem__(self, key):
+        if isinstance(key, (slice, np.ndarray)):
+            # (the fields of a Photons object have their types already: a slice or a gather of it needs no conversion --
+            #  Simulation hands out tens of thousands of per-channel slices per event)
+            out = object.__new__(Photons)
+            d = self.__dict__
+            out.__dict__ = {name: d[name][key] for name in _PHOTON_FIELDS}
+            return out
         return Photons(*[a[key] for a in self._fields()])
 
     def __str__(self):

@@ -163,9 +163,10 @@ class Simulation(object):
                 ev_hits = per_event_hits[i]
                 if keep_hits:
                     # (the event's hits are in channel order already: a channel's hits are one slice)
-                    channels, first = np.unique(ev_hits.channel, return_index=True)
-                    last = np.append(first[1:], len(ev_hits))
-                    ev.hits = {int(ch): ev_hits[a:b] for ch, a, b in zip(channels, first, last)}
+                    ch = ev_hits.channel
+                    first = np.flatnonzero(np.concatenate(([True], ch[1:] != ch[:-1]))) if len(ch) else np.zeros(0, np.intp)
+                    last = np.append(first[1:], len(ch))
+                    ev.hits = {c: ev_hits[a:b] for c, a, b in zip(ch[first].tolist(), first.tolist(), last.tolist())}
                 if keep_flat_hits:
                     ev.flat_hits = ev_hits
             if hasattr(self, 'gpu_daq') and run_daq:

@@ -46,3 +46,11 @@ for prefetch in (False, True):
     dt = time.perf_counter() - t0
     print('Simulation.simulate, %d batches of %d host photons, prefetch=%s: %.3f s -> %.3g photons/s end to end (%d flat hits on the host)' % (
         nb, n, prefetch, dt, nb * n / dt, nhits), flush=True)
+# ... and with the per-channel dictionaries of the DEFAULT call (keep_hits=True: ev.hits, chroma/sim.py:122-123), which the
+# reference builds with one mask over all hits per channel and this package from one ordering of the hits (chroma_amd/sim.py)
+sim0.prefetch = True
+t0 = time.perf_counter()
+nch = sum(len(ev.hits) for ev in sim0.simulate([host] * 2, photons_per_batch=n, max_steps=100))
+dt = time.perf_counter() - t0
+print('Simulation.simulate, 2 batches of %d host photons, keep_hits=True (default): %.3f s -> %.3g photons/s end to end (%d channel entries)' % (
+    n, dt, 2 * n / dt, nch), flush=True)
