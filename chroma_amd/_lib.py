@@ -169,6 +169,7 @@ SIGNATURES = {
                                    POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint32)]),
     'chroma_bvh_build_device': (c_int32, [c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, POINTER(c_float), c_float, c_int32,
                                           POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint32)]),
+    'chroma_hits_sort': (c_int32, [c_void_p, POINTER(PhotonArrays), c_void_p, c_uint64]),
     'chroma_photons_sort_direction': (c_int32, [c_void_p, POINTER(PhotonArrays), c_uint64]),
     'chroma_bvh_fetch': (c_int32, [c_void_p, c_void_p, c_void_p]),
     'chroma_bvh_data': (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p)]),

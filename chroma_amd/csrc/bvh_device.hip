@@ -445,6 +445,59 @@ extern "C" int chroma_photons_sort_direction(chroma_ctx *ctx, const chroma_photo
     return CHROMA_OK;
 }
 
+// ---- flat hits in (event, channel) order ---------------------------------------------------------------------------------
+// What a caller does next with a batch's flat hits (chroma/sim.py:118-123, chroma/gpu/photon.py:96-105) is to split them by event
+// and by channel -- the reference with one boolean mask over all hits per event and per channel.  Ordered here, on the device, a
+// split is a slice: a 64-bit key (evidx, channel) per hit, a stable radix sort of (key, slot), every array gathered through it.
+// The order of flat hits is unspecified in the reference (its compaction goes through an atomic); this one is a valid instance.
+namespace {
+__global__ void k_hit_keys(const uint32_t *evidx, const int32_t *channels, uint32_t n, unsigned long long *keys, uint32_t *ids)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = ((unsigned long long)(evidx ? evidx[i] : 0u) << 32) | (uint32_t)channels[i];
+    ids[i] = i;
+}
+}  // namespace
+
+extern "C" int chroma_hits_sort(chroma_ctx *ctx, const chroma_photon_arrays *hits, int32_t *d_channels, uint64_t nhits)
+{
+    if (!ctx || !hits || !d_channels) return chroma_internal_set_error(CHROMA_ERR_INVALID, "chroma_hits_sort: bad argument");
+    if (nhits >= 0x7fffffffull) return chroma_internal_set_error(CHROMA_ERR_INVALID, "at most 2^31-2 hits per call");
+    if (nhits < 2) return CHROMA_OK;
+    hipStream_t stream = chroma_internal_stream(ctx);
+    DEV_TRY(hipSetDevice(chroma_internal_device(ctx)));
+    const uint32_t n = (uint32_t)nhits;
+    Arena arena;
+    arena.ctx = ctx;
+    unsigned long long *d_keys, *d_keys_sorted;
+    uint32_t *d_ids, *d_order, *d_buf;
+    DEV_TRY(arena.get(&d_keys, n)); DEV_TRY(arena.get(&d_keys_sorted, n));
+    DEV_TRY(arena.get(&d_ids, n)); DEV_TRY(arena.get(&d_order, n));
+    hipLaunchKernelGGL(k_hit_keys, dim3(blocks_for(n)), dim3(256), 0, stream, (const uint32_t *)hits->evidx, (const int32_t *)d_channels, n, d_keys, d_ids);
+    size_t tmp_bytes = 0;
+    DEV_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_ids, d_order, (int)n, 0, 64, stream));
+    uint8_t *d_tmp;
+    DEV_TRY(arena.get(&d_tmp, tmp_bytes));
+    DEV_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_ids, d_order, (int)n, 0, 64, stream));
+    DEV_TRY(arena.get(&d_buf, 3 * (size_t)n));
+    float *f3[3] = {hits->pos, hits->dir, hits->pol};
+    for (float *a : f3) {
+        if (!a) continue;
+        hipLaunchKernelGGL((k_gather_words<3>), dim3(blocks_for(n)), dim3(256), 0, stream, (const uint32_t *)a, d_order, n, d_buf);
+        DEV_TRY(hipMemcpyAsync(a, d_buf, 3 * (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    void *w1[8] = {hits->wavelengths, hits->t, hits->flags, hits->last_hit_triangles, hits->weights, hits->evidx, hits->rng_counters, d_channels};
+    for (void *a : w1) {
+        if (!a) continue;
+        hipLaunchKernelGGL((k_gather_words<1>), dim3(blocks_for(n)), dim3(256), 0, stream, (const uint32_t *)a, d_order, n, d_buf);
+        DEV_TRY(hipMemcpyAsync(a, d_buf, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    DEV_TRY(hipGetLastError());
+    DEV_TRY(hipStreamSynchronize(stream));
+    return CHROMA_OK;
+}
+
 // ---- the order in which chroma_propagate takes up the photons of a POINT-LIKE source that arrive in no particular order ----
 // (chroma_hip.hip: propagate_order).  A 16-bit cell of the direction on an octahedral map of the sphere (no arc functions; a
 // heuristic that steers speed only -- results are stored by photon id and drawn from per-photon streams), Morton-interleaved

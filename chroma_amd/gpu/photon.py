@@ -188,7 +188,7 @@ class GPUPhotons(object):
     @profile_if_possible
     def propagate_hits(self, gpu_detector, rng_states, max_steps=10, use_weights=False, scatter_first=0, target_flag=(0x1 << 2),
                        capacity=None, channel_arrays=None, stats=None, time_kernels=False, exact=False,
-                       nthreads_per_block=64, max_blocks=1024):
+                       nthreads_per_block=64, max_blocks=1024, sort=False):
         """``propagate`` followed by ``get_flat_hits`` as ONE library call (chroma_propagate_hits): the pass that finishes
         the propagation also counts and compacts the detected photons with their channels (chroma/gpu/photon.py:96-175) and,
         when ``channel_arrays=(counts, earliest)`` (device arrays of nchannels uint32) is given, accumulates the per-channel
@@ -225,7 +225,10 @@ class GPUPhotons(object):
             print("WARNING: ABORTED PHOTONS", file=sys.stderr)
         n = int(req.nhits)
         if n > capacity:
-            return self.get_flat_hits(gpu_detector, target_flag=target_flag)
+            return self.get_flat_hits(gpu_detector, target_flag=target_flag, sort=sort)
+        if sort and n > 1:
+            # (event, channel) order on the device (chroma_hits_sort): the caller's split by event and channel is slicing
+            _lib.check(lib.chroma_hits_sort(ctx.handle, ctypes.byref(dst), channels.ptr, n))
         w = slice(0, n)
         p = GPUPhotonsSlice(pos=out.pos[w], dir=out.dir[w], pol=out.pol[w], wavelengths=out.wavelengths[w], t=out.t[w],
                             last_hit_triangles=out.last_hit_triangles[w], flags=out.flags[w], weights=out.weights[w],
@@ -266,19 +269,22 @@ class GPUPhotons(object):
 
     def get_hits(self, *args, **kwargs):
         """dict channel -> Photons detected on that channel."""
-        flat = self.get_flat_hits(*args, **kwargs)
-        # one stable sort by channel and slices of it (chroma/gpu/photon.py:96-105 masks all hits once per channel): the same
-        # photons per channel in the same order
-        keys = flat.channel.astype(np.uint16) if len(flat) and int(flat.channel.max()) < 65536 else flat.channel
-        by_channel = flat[np.argsort(keys, kind='stable')]
-        channels, first = np.unique(by_channel.channel, return_index=True)
-        last = np.append(first[1:], len(by_channel))
-        return {int(ch): by_channel[a:b] for ch, a, b in zip(channels, first, last)}
+        # the hits put in channel order on the device, then slices (chroma/gpu/photon.py:96-105 masks all hits once per
+        # channel): the same photons per channel.  (Copies of one photon set share evidx 0 .. so the device order by
+        # (evidx, channel) is re-grouped by channel alone here when there is more than one event index.)
+        flat = self.get_flat_hits(*args, sort=True, **kwargs)
+        if len(flat) and int(flat.evidx.max()) != int(flat.evidx.min()):
+            flat = flat[np.argsort(flat.channel, kind='stable')]
+        ch = flat.channel
+        first = np.flatnonzero(np.concatenate(([True], ch[1:] != ch[:-1]))) if len(ch) else np.zeros(0, np.intp)
+        last = np.append(first[1:], len(ch))
+        return {c: flat[a:b] for c, a, b in zip(ch[first].tolist(), first.tolist(), last.tolist())}
 
     def get_flat_hits(self, gpu_detector, target_flag=(0x1 << 2), nthreads_per_block=64, max_blocks=1024,
-                      start_photon=None, nphotons=None, no_map=False):
+                      start_photon=None, nphotons=None, no_map=False, sort=False):
         """Photons with ``target_flag`` set whose last hit triangle belongs to a channel, plus
-        that channel (chroma/gpu/photon.py:107-175).  Order is unspecified, as in the reference."""
+        that channel (chroma/gpu/photon.py:107-175).  Order is unspecified, as in the reference; ``sort=True``: in
+        (evidx, channel) order, made on the device (chroma_hits_sort)."""
         if start_photon is None:
             start_photon = 0
         if nphotons is None:
@@ -297,6 +303,8 @@ class GPUPhotons(object):
             _lib.check(lib.chroma_copy_photon_hits(ctx.handle, gpu_detector.handle, start_photon, nphotons, int(target_flag),
                                                    ctypes.byref(src), ctypes.byref(dst), channels.ptr, ctypes.byref(ncopied)))
             assert ncopied.value == n
+            if sort and n > 1:
+                _lib.check(lib.chroma_hits_sort(ctx.handle, ctypes.byref(dst), channels.ptr, n))
         p = out.get()
         p.channel = channels.get().astype(np.uint32) if n else np.zeros(0, dtype=np.uint32)
         return p

@@ -19,15 +19,6 @@ def pick_seed():
     return int(time.time()) ^ (os.getpid() << 16) & 2 ** 32 - 1
 
 
-def _stable_order(keys):
-    """argsort(keys, kind='stable'); small non-negative integer keys (channels, event indices) go through NumPy's radix
-    sort for 16-bit integers instead of a merge sort."""
-    k = np.asarray(keys)
-    if len(k) and k.dtype.kind in 'iu' and int(k.min()) >= 0 and int(k.max()) < 65536:
-        k = k.astype(np.uint16)
-    return np.argsort(k, kind='stable')
-
-
 class Simulation(object):
     def __init__(self, detector, seed=None, cuda_device=None, particle_tracking=False, photon_tracking=False,
                  geant4_processes=0, nthreads_per_block=64, max_blocks=1024, exact=False, prefetch=True, lanes=1):
@@ -109,7 +100,7 @@ class Simulation(object):
         batch_hits = tracking = None
         if want_hits and not self.photon_tracking:
             # propagate + get_flat_hits as one library call (chroma_propagate_hits): the same set of hits
-            batch_hits = gpu_photons.propagate_hits(geometry, self.rng_states, max_steps=max_steps, exact=self.exact)
+            batch_hits = gpu_photons.propagate_hits(geometry, self.rng_states, max_steps=max_steps, exact=self.exact, sort=True)
         else:
             tracking = gpu_photons.propagate(geometry, self.rng_states,
                                              nthreads_per_block=self.nthreads_per_block, max_blocks=self.max_blocks,
@@ -121,26 +112,19 @@ class Simulation(object):
 
         batch_end = gpu_photons.get() if keep_photons_end else None
         if want_hits and batch_hits is None:
-            batch_hits = gpu_photons.get_flat_hits(geometry)
+            batch_hits = gpu_photons.get_flat_hits(geometry, sort=True)
 
-        # The hits of each event, and within an event of each channel: ONE ordering of the batch's hits -- by channel, then
-        # (stably) by event -- one gather, and slices of it (views), instead of one boolean mask over all hits per event and
-        # then per channel (chroma/sim.py:118-123: hits x events + hits x channels element tests -- 2e11 for one 1e8-photon
-        # batch on a 29k-channel detector).  Keys below 65 536 are sorted as uint16, which NumPy sorts by radix.
+        # The hits of each event, and within an event of each channel, are SLICES: the library hands the batch's hits over in
+        # (event, channel) order (chroma_hits_sort: a radix sort and a gather on the device), where the reference masks all
+        # hits once per event and once per channel (chroma/sim.py:118-123: hits x events + hits x channels element tests --
+        # 2e11 for one 1e8-photon batch on a 29k-channel detector).
         per_event_hits = None
         if batch_hits is not None:
-            order = None
-            if keep_hits and len(batch_hits):
-                order = _stable_order(batch_hits.channel)
-            if len(batch_events) > 1 and len(batch_hits):
-                by_event = _stable_order(batch_hits.evidx if order is None else batch_hits.evidx[order])
-                order = by_event if order is None else order[by_event]
-            sorted_hits = batch_hits if order is None else batch_hits[order]
             if len(batch_events) == 1:
-                per_event_hits = [sorted_hits]
+                per_event_hits = [batch_hits]
             else:
-                cuts = np.searchsorted(sorted_hits.evidx, np.arange(len(batch_events) + 1))
-                per_event_hits = [sorted_hits[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+                cuts = np.searchsorted(batch_hits.evidx, np.arange(len(batch_events) + 1))
+                per_event_hits = [batch_hits[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
         for i, (ev, lo, hi) in enumerate(zip(batch_events, bounds[:-1], bounds[1:])):
             if not keep_photons_beg:
                 ev.photons_beg = None

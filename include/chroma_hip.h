@@ -383,6 +383,12 @@ int chroma_generate_bomb(chroma_ctx *ctx, const chroma_photon_arrays *photons, u
  * (chroma/benchmark.py:80-82); bench.py does the same to its bomb.  Slot i afterwards holds the photon of rank i. */
 int chroma_photons_sort_direction(chroma_ctx *ctx, const chroma_photon_arrays *photons, uint64_t nphotons);
 
+/* Flat hits (what chroma_copy_photon_hits / chroma_propagate_hits left in `hits` and `d_channels`) put in (evidx, channel) order, in
+ * place and stably: the split by event and by channel that the reference's callers do next with one mask over all hits per event and
+ * per channel (chroma/sim.py:118-123, chroma/gpu/photon.py:96-105) is then a matter of slices.  The reference leaves the order of
+ * flat hits unspecified (its compaction goes through an atomic); this is one valid order. */
+int chroma_hits_sort(chroma_ctx *ctx, const chroma_photon_arrays *hits, int32_t *d_channels, uint64_t nhits);
+
 /* `render` (chroma/cuda/render.cu:37-181): every triangle along each ray, the `alpha_depth` nearest kept as
  * a per-ray list sorted by distance (d_dx [n][alpha_depth], d_color [n][alpha_depth][4], d_dxlen [n]: in and
  * out, so that a second call continues the first -- GPURays.render(keep_last_render=True)), composited

@@ -107,3 +107,40 @@ def test_every_surface_model_and_the_exact_walk(gpu):
 def test_weights(gpu, tiny_geometry):
     gg = gpu.GPUDetector(tiny_geometry)
     both_ways(gpu, gg, bomb(30000, 12), 30, use_weights=True)
+
+
+def test_hits_in_event_and_channel_order_on_the_device(gpu, tiny_geometry):
+    """chroma_hits_sort (get_flat_hits(sort=True), propagate_hits(sort=True)): the same SET of flat hits as without, in
+    (evidx, channel) order -- what lets Simulation and get_hits split a batch's hits by slicing where the reference masks all
+    hits once per event and per channel (chroma/sim.py:118-123, chroma/gpu/photon.py:96-105).  Also with a capacity too small
+    (the fall-back path), with no hit at all, and through get_hits."""
+    gg = gpu.GPUDetector(tiny_geometry)
+    ph = bomb(120000, 41)
+    ph.evidx[:] = np.random.default_rng(3).integers(0, 7, len(ph)).astype(np.uint32)
+    a = gpu.GPUPhotons(ph)
+    a.propagate(gg, gpu.get_rng_states(64, seed=9), max_steps=100)
+    plain = a.get_flat_hits(gg)
+    ordered = a.get_flat_hits(gg, sort=True)
+    assert len(plain) == len(ordered) > 1000 and len(np.unique(ordered.evidx)) == 7
+    key = ordered.evidx.astype(np.uint64) << np.uint64(32) | ordered.channel.astype(np.uint64)
+    assert (np.diff(key.astype(np.int64)) >= 0).all(), 'not in (evidx, channel) order'
+    for f in FIELDS + ('evidx', 'channel'):
+        x, y = getattr(canonical(plain), f), getattr(canonical(ordered), f)
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), f
+    for capacity in (None, 100):
+        b = gpu.GPUPhotons(ph)
+        fused = b.propagate_hits(gg, gpu.get_rng_states(64, seed=9), max_steps=100, capacity=capacity, sort=True)
+        k2 = fused.evidx.astype(np.uint64) << np.uint64(32) | fused.channel.astype(np.uint64)
+        assert len(fused) == len(plain) and (np.diff(k2.astype(np.int64)) >= 0).all()
+        assert np.array_equal(canonical(fused).t.view(np.uint32), canonical(plain).t.view(np.uint32))
+    # get_hits: per channel the photons the reference's mask selects
+    hitmap = a.get_hits(gg)
+    assert sorted(hitmap) == sorted(int(c) for c in np.unique(plain.channel))
+    for ch in list(hitmap)[:50]:
+        want = plain[plain.channel == ch]
+        got = hitmap[ch]
+        assert len(got) == len(want) and (got.channel == ch).all()
+        assert np.array_equal(np.sort(got.t.view(np.uint32)), np.sort(want.t.view(np.uint32)))
+    # nothing detected: nothing to sort
+    none = gpu.GPUPhotons(bomb(1000, 42))
+    assert len(none.get_flat_hits(gg, sort=True)) == 0 and none.get_hits(gg) == {}
